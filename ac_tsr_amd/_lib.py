@@ -1,0 +1,112 @@
+"""ctypes binding of libacattn.so -- the C ABI declared in include/acattn.h.
+
+The structures below mirror the header field for field.  There is NO fallback: if the shared
+library has not been built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C ac_tsr_amd/csrc``) importing any compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libacattn.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
+
+ABI_VERSION = 1
+NSTAT = 8
+MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
+COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
+RICH = {"none": 0, "fixed": 1, "trainable": 2}
+RNG_EXPLICIT, RNG_COUNTER = 0, 1
+
+_f = C.c_void_p  # every device pointer travels as an integer address
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("n_heads", C.c_int32),
+        ("q", _f), ("k", _f), ("v", _f), ("qa", _f), ("ka", _f), ("gate_logits", _f),
+        ("mask_mode", C.c_int32), ("causal", C.c_int32), ("key_valid", _f), ("mask", _f),
+        ("w_order", _f), ("b_order", _f), ("w_dist", _f), ("b_dist", _f), ("scalar", _f),
+        ("adversarial", C.c_int32), ("combine_option", C.c_int32), ("anneal_rate", C.c_float),
+        ("two_level", C.c_int32), ("rich_combine", C.c_int32), ("rich_ratio", _f),
+        ("rng_mode", C.c_int32), ("p_drop", C.c_float), ("noise", _f), ("keep_after", _f), ("keep_before", _f),
+        ("keep_mask", _f), ("seed", C.c_uint64),
+    ]
+
+
+class FwdOut(C.Structure):
+    _fields_ = [
+        ("ctx_attacked", _f), ("ctx_calibrated", _f), ("attack_mask", _f), ("row_stats", _f),
+        ("after_spatial", _f), ("before_spatial", _f), ("perturbed_attention", _f), ("calibrated_attention", _f),
+    ]
+
+
+class BwdIO(C.Structure):
+    _fields_ = [
+        ("attack_mask", _f), ("row_stats", _f),
+        ("d_ctx_attacked", _f), ("d_ctx_calibrated", _f), ("d_attack_mask", _f),
+        ("dq", _f), ("dk", _f), ("dv", _f), ("dqa", _f), ("dka", _f), ("dgate_logits", _f),
+        ("dw_order_part", _f), ("dw_dist_part", _f), ("dsmall_part", _f),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/acattn.h declares (tests check this)
+SYMBOLS = {
+    "acattn_abi_version": (C.c_int, []),
+    "acattn_last_error": (C.c_char_p, []),
+    "acattn_fwd_algorithmic_bytes": (C.c_int64, [C.POINTER(Problem)]),
+    "acattn_calibrated_attention_fwd": (C.c_int, [C.POINTER(Problem), C.POINTER(FwdOut), C.c_void_p]),
+    "acattn_calibrated_attention_bwd": (C.c_int, [C.POINTER(Problem), C.POINTER(BwdIO), C.c_void_p]),
+    "acattn_rng_materialize": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, _f, _f, _f, _f,
+                                         C.c_void_p]),
+}
+
+_lib = None
+
+
+class AcattnError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libacattn.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    jobs = str(min(4, os.cpu_count() or 1))
+    res = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        raise AcattnError("building libacattn.so failed:\n" + (res.stdout or "") + (res.stderr or ""))
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AcattnError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`make -C ac_tsr_amd/csrc` (or __graft_entry__.build()). There is no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.acattn_abi_version()
+    if got != ABI_VERSION:
+        raise AcattnError(f"libacattn.so ABI {got} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    msg = load().acattn_last_error().decode()
+    if rc < 0 and "not a multiple of the number of attention" in msg:
+        raise ValueError(msg)  # same exception type as recbole/model/layers.py:618-622
+    if rc < 0 and ("unknown combine_option" in msg or "unknown rich_calibrated_combine" in msg):
+        raise KeyError(msg)  # recbole/model/layers.py:894-895, 935-936
+    raise AcattnError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,109 @@
+// C-ABI entry points of libacattn.so (include/acattn.h): argument validation, dispatch, error text.
+#include <stdio.h>
+#include <string.h>
+
+#include "acattn_common.h"
+
+namespace {
+thread_local char g_err[256] = "";
+
+int fail(const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return -1;
+}
+
+int check_problem(const acattn_problem* p) {
+  if (!p) return fail("problem is NULL");
+  if (p->B < 1 || p->L < 1 || p->H < 1 || p->n_heads < 1) return fail("B, L, H, n_heads must be positive");
+  if (p->H % p->n_heads != 0)
+    return fail("The hidden size is not a multiple of the number of attention heads");  // layers.py:618-622
+  const int dh = p->H / p->n_heads;
+  if (dh != 16 && dh != 32 && dh != 64) return fail("unsupported head size: dh must be 16, 32 or 64");
+  if (p->L > 208) return fail("unsupported sequence length: L must be <= 208");
+  if (!p->q || !p->k || !p->v) return fail("q, k, v must be non-NULL");
+  if (p->mask_mode == ACATTN_MASK_STRUCTURED) {
+    if (!p->key_valid) return fail("structured mask needs key_valid");
+  } else if (p->mask_mode == ACATTN_MASK_DENSE_LL || p->mask_mode == ACATTN_MASK_DENSE_L) {
+    if (!p->mask) return fail("dense mask mode needs mask");
+  } else {
+    return fail("unknown mask_mode");
+  }
+  if (p->w_order && !p->b_order) return fail("w_order given without b_order");
+  if (p->w_dist && (!p->b_dist || !p->scalar)) return fail("w_dist given without b_dist / scalar");
+  if (p->p_drop < 0.f || p->p_drop >= 1.f) return fail("p_drop must lie in [0, 1)");
+  if (p->rng_mode != ACATTN_RNG_EXPLICIT && p->rng_mode != ACATTN_RNG_COUNTER) return fail("unknown rng_mode");
+  if (p->rng_mode == ACATTN_RNG_EXPLICIT && p->p_drop > 0.f) {
+    if (!p->keep_after) return fail("explicit dropout needs keep_after");
+    if (p->adversarial && !p->keep_mask) return fail("explicit dropout needs keep_mask");
+    if (p->adversarial && !p->two_level && !p->keep_before) return fail("explicit dropout needs keep_before");
+  }
+  if (p->adversarial) {
+    if (!p->qa || !p->ka) return fail("adversarial calibrator needs qa and ka");
+    if (p->rng_mode == ACATTN_RNG_EXPLICIT && !p->noise) return fail("explicit rng mode needs noise");
+    if (p->combine_option == ACATTN_COMBINE_GATE) {
+      if (!p->gate_logits) return fail("combine_option gate needs gate_logits");
+    } else if (p->combine_option != ACATTN_COMBINE_FIXED && p->combine_option != ACATTN_COMBINE_ANNEALING) {
+      return fail("unknown combine_option");  // layers.py:894-895 raises KeyError
+    }
+    if (!p->two_level) {
+      if (p->rich_combine != ACATTN_RICH_FIXED && p->rich_combine != ACATTN_RICH_TRAINABLE)
+        return fail("unknown rich_calibrated_combine");  // layers.py:935-936 raises KeyError
+      if (p->rich_combine == ACATTN_RICH_TRAINABLE && !p->rich_ratio) return fail("trainable rich combine needs rich_ratio");
+    }
+  }
+  return 0;
+}
+}  // namespace
+
+void acattn_set_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+
+extern "C" {
+
+int acattn_abi_version(void) { return ACATTN_ABI_VERSION; }
+
+const char* acattn_last_error(void) { return g_err; }
+
+int64_t acattn_fwd_algorithmic_bytes(const acattn_problem* p) {
+  if (!p) return -1;
+  const int64_t t_lh = 4LL * p->L * p->H, t_ll = 4LL * p->L * p->L;
+  if (!p->adversarial) return (int64_t)p->B * 4 * t_lh;  // contract A': read q,k,v, write one context
+  // contract A: read q,k,v,qa,ka (+ gate logits), write two contexts + M (noise generated in-kernel)
+  int64_t per_seq = 7 * t_lh + (int64_t)p->n_heads * t_ll;
+  if (p->combine_option == ACATTN_COMBINE_GATE) per_seq += t_ll;
+  return (int64_t)p->B * per_seq;
+}
+
+int acattn_calibrated_attention_fwd(const acattn_problem* p, const acattn_fwd_out* out, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (!out) return fail("out is NULL");
+  if (!out->ctx_calibrated) return fail("ctx_calibrated must be non-NULL");
+  if (p->adversarial && (!out->ctx_attacked || !out->attack_mask))
+    return fail("adversarial forward needs ctx_attacked and attack_mask outputs");
+  const int rc = acattn_launch_fwd(*p, *out, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_calibrated_attention_bwd(const acattn_problem* p, const acattn_bwd_io* io, void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (!io) return fail("io is NULL");
+  if (!p->adversarial) return fail("backward is defined for the adversarial (full) operator only");
+  if (!io->attack_mask || !io->row_stats) return fail("backward needs the forward's attack_mask and row_stats");
+  if (!io->dq || !io->dk || !io->dv || !io->dqa || !io->dka) return fail("dq, dk, dv, dqa, dka must be non-NULL");
+  if (p->combine_option == ACATTN_COMBINE_GATE && !io->dgate_logits) return fail("gate combine needs dgate_logits");
+  if (!io->dw_order_part || !io->dw_dist_part || !io->dsmall_part) return fail("parameter partial buffers must be non-NULL");
+  const int rc = acattn_launch_bwd(*p, *io, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_rng_materialize(int32_t B, int32_t n_heads, int32_t L, uint64_t seed, float p_drop, float* noise,
+                           uint8_t* keep_after, uint8_t* keep_mask, uint8_t* keep_before, void* stream) {
+  if (B < 1 || n_heads < 1 || L < 1) return fail("B, n_heads, L must be positive");
+  const int rc = acattn_launch_rng(B, n_heads, L, seed, p_drop, noise, keep_after, keep_mask, keep_before,
+                                   (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+}  // extern "C"

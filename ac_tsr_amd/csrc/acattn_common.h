@@ -1,0 +1,117 @@
+// Device-side helpers shared by the forward and backward kernels of the calibrated-attention core.
+// gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, fp32 MFMA 16x16x4, permlane swaps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "acattn.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+// 4 floats at dword alignment: rows of an [.., L, L] tensor with L % 4 != 0 start 8 bytes off;
+// gfx950 global memory takes dword-aligned dwordx4 accesses.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+#define ACATTN_NEG_INF (-__builtin_inff())
+#define ACATTN_MASK_FILL (-10000.0f)  // recbole/model/abstract_recommender.py:142
+#define ACATTN_LOG_EPS (1e-24f)       // recbole/model/layers.py:719
+
+// Lane layout used by every kernel here: lane = 16*g + c with c = lane & 15 (query row inside a
+// 16-row block) and g = lane >> 4 (which quarter of every 16-key tile the lane holds).
+// A query row's keys live in the registers of its four lanes {c, c+16, c+32, c+48}; the helpers
+// below reduce over those four lanes with two VALU permlane swaps (no LDS traffic).
+__device__ __forceinline__ float quad_sum(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
+__device__ __forceinline__ float quad_max(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+}
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+  // D[16x16] += A[16x4] . B[4x16]; lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
+  // D register r of lane l is D[4*(l>>4) + r][l&15].  Exact fp32 (a k-ordered fmaf chain).
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based randomness (ACATTN_RNG_COUNTER).  One call yields, for the 4 consecutive keys
+// j0..j0+3 of one query row, 4 standard normals (Box-Muller) and the two dropout keep decisions
+// per key.  The stream depends only on (seed, row id, key group), so the backward kernel and
+// acattn_rng_materialize() regenerate it exactly.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+struct RngGroup {
+  float n[4];
+  uint32_t keep_after;  // bit r set = keep
+  uint32_t keep_mask;
+  uint32_t keep_before;
+};
+
+// row_id = (b * n_heads + h) * L + i ; grp = j0 / 4.
+__device__ __forceinline__ RngGroup rng_group(uint64_t seed, uint32_t row_id, uint32_t grp, float p_drop) {
+  const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+  const uint32_t base = mix32((row_id * 64u + grp) ^ s_lo) + s_hi;
+  uint32_t w[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) w[k] = mix32(base + (uint32_t)(k + 1) * 0x9E3779B9u);
+  RngGroup o;
+#pragma unroll
+  for (int pair = 0; pair < 2; ++pair) {
+    const float u1 = (float)((w[2 * pair] >> 8) + 1u) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(w[2 * pair + 1] >> 8) * (1.0f / 16777216.0f);     // [0, 1) revolutions
+    const float rad = __fsqrt_rn(-2.0f * __logf(u1));
+    o.n[2 * pair] = rad * __builtin_amdgcn_cosf(u2);
+    o.n[2 * pair + 1] = rad * __builtin_amdgcn_sinf(u2);
+  }
+  const uint32_t thr = (uint32_t)(p_drop * 65536.0f);  // keep iff 16 random bits >= thr
+  o.keep_after = 0;
+  o.keep_mask = 0;
+  o.keep_before = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t ba = (w[4 + (r >> 1)] >> (16 * (r & 1))) & 0xFFFFu;
+    const uint32_t bm = (w[6 + (r >> 1)] >> (16 * (r & 1))) & 0xFFFFu;
+    const uint32_t bb = (w[8 + (r >> 1)] >> (16 * (r & 1))) & 0xFFFFu;
+    o.keep_after |= (ba >= thr ? 1u : 0u) << r;
+    o.keep_mask |= (bm >= thr ? 1u : 0u) << r;
+    o.keep_before |= (bb >= thr ? 1u : 0u) << r;
+  }
+  return o;
+}
+
+// Block index -> (b, head).  Workgroups b and b+8 share an XCD (round-robin dispatch), so the heads
+// of one sequence are placed 8 blocks apart: they read the same gate-logit tile from one L2.
+// Pure speed hint; any placement gives the same results.
+__device__ __forceinline__ void decode_block(int bid, int B, int nh, int& b, int& h) {
+  if ((B & 7) == 0) {
+    const int grp = bid / (8 * nh), rem = bid - grp * 8 * nh;
+    h = rem >> 3;
+    b = grp * 8 + (rem & 7);
+  } else {
+    b = bid / nh;
+    h = bid - b * nh;
+  }
+}
+
+// Host-side launchers (defined in the .hip files, called from acattn_api.hip).
+int acattn_launch_fwd(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
+int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
+int acattn_launch_rng(int B, int nh, int L, uint64_t seed, float p_drop, float* noise, uint8_t* keep_after,
+                      uint8_t* keep_mask, uint8_t* keep_before, hipStream_t stream);
+void acattn_set_error(const char* msg);

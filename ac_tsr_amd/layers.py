@@ -1,0 +1,235 @@
+"""MI355X-native modules with the reference's operator surface for the calibrated encoder.
+
+Class names, constructor signatures, forward signatures / return arities and state-dict keys are
+those of recbole/model/layers.py (AttackRMultiHeadAttention :614-742, FeedForward :745-798,
+AttackRTransformerLayer :859-951, AttackRTransformerEncoder :1070-1131), so a checkpoint of the
+reference loads with `load_state_dict` and the AC-SASRec trainer can drive these modules unchanged.
+The attention core itself is NOT a chain of torch ops: every layer makes one call into the HIP
+library (`ops.calibrated_attention`); the dense projections around it stay rocBLAS GEMMs.
+
+Extra, optional keyword arguments (absent from the reference) are prefixed with an underscore:
+`_rnd` feeds explicit randomness for parity tests.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .ops import AttentionConfig, ExplicitRandomness, StructuredMask
+
+
+class AttackRMultiHeadAttention(nn.Module):
+    """Parameters and projections of recbole/model/layers.py:614-650.  The three methods of the
+    reference (`cal_origin_qkv`, `cal_attack_mask`, `cal_adjusted_outputs`) are fused: `project` yields
+    the five projected tensors the HIP core consumes, `output` is the dense + residual LayerNorm tail
+    of `cal_adjusted_outputs` (:681-683)."""
+
+    def __init__(self, n_heads, hidden_size, hidden_dropout_prob, attn_dropout_prob, layer_norm_eps, use_order,
+                 use_distance):
+        super().__init__()
+        if hidden_size % n_heads != 0:
+            raise ValueError(
+                "The hidden size (%d) is not a multiple of the number of attention "
+                "heads (%d)" % (hidden_size, n_heads))
+        self.num_attention_heads = n_heads
+        self.attention_head_size = int(hidden_size / n_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.sqrt_attention_head_size = math.sqrt(self.attention_head_size)
+
+        self.query = nn.Linear(hidden_size, self.all_head_size)
+        self.key = nn.Linear(hidden_size, self.all_head_size)
+        self.value = nn.Linear(hidden_size, self.all_head_size)
+
+        self.use_order = use_order
+        self.use_distance = use_distance
+        if self.use_order:
+            self.order_affine = nn.Linear(2 * self.attention_head_size, 1)
+        if self.use_distance:
+            self.distance_affine = nn.Linear(2 * self.attention_head_size, 1)
+            self.scalar = nn.Parameter(torch.randn(1))
+
+        self.attack_query_transform = nn.Linear(self.all_head_size, self.all_head_size)
+        self.attack_key_transform = nn.Linear(self.all_head_size, self.all_head_size)
+
+        self.attn_dropout_prob = attn_dropout_prob
+        self.dense = nn.Linear(hidden_size, hidden_size)
+        self.LayerNorm = nn.LayerNorm(hidden_size, eps=layer_norm_eps)
+        self.out_dropout = nn.Dropout(hidden_dropout_prob)
+
+    def project(self, input_tensor):
+        """mixed q/k/v (layers.py:687-689) and the attack transforms of the MIXED q/k (:658-659)."""
+        mq = self.query(input_tensor)
+        mk = self.key(input_tensor)
+        mv = self.value(input_tensor)
+        qa = self.attack_query_transform(mq)
+        ka = self.attack_key_transform(mk)
+        return mq, mk, mv, qa, ka
+
+    def calibrator_params(self):
+        p = {}
+        if self.use_order:
+            p.update(w_order=self.order_affine.weight, b_order=self.order_affine.bias)
+        if self.use_distance:
+            p.update(w_dist=self.distance_affine.weight, b_dist=self.distance_affine.bias, scalar=self.scalar)
+        return p
+
+    def output(self, context_layer, input_tensor, _keep=None):
+        """dense -> dropout -> LayerNorm(+residual) of cal_adjusted_outputs (layers.py:681-683)."""
+        hidden_states = self.dense(context_layer)
+        if _keep is not None:
+            hidden_states = hidden_states * (_keep.to(hidden_states.dtype) / (1.0 - self.out_dropout.p))
+        else:
+            hidden_states = self.out_dropout(hidden_states)
+        return self.LayerNorm(hidden_states + input_tensor)
+
+
+class FeedForward(nn.Module):
+    """recbole/model/layers.py:745-798 (exact-erf gelu)."""
+
+    def __init__(self, hidden_size, inner_size, hidden_dropout_prob, hidden_act, layer_norm_eps):
+        super().__init__()
+        self.dense_1 = nn.Linear(hidden_size, inner_size)
+        self.intermediate_act_fn = self.get_hidden_act(hidden_act)
+        self.dense_2 = nn.Linear(inner_size, hidden_size)
+        self.LayerNorm = nn.LayerNorm(hidden_size, eps=layer_norm_eps)
+        self.dropout = nn.Dropout(hidden_dropout_prob)
+
+    def get_hidden_act(self, act):
+        ACT2FN = {
+            "gelu": self.gelu,
+            "relu": F.relu,
+            "swish": self.swish,
+            "tanh": torch.tanh,
+            "sigmoid": torch.sigmoid,
+        }
+        return ACT2FN[act]
+
+    def gelu(self, x):
+        return F.gelu(x)  # erf form == x * 0.5 * (1 + erf(x / sqrt(2)))  (layers.py:785)
+
+    def swish(self, x):
+        return x * torch.sigmoid(x)
+
+    def forward(self, input_tensor, _keep=None):
+        hidden_states = self.dense_2(self.intermediate_act_fn(self.dense_1(input_tensor)))
+        if _keep is not None:
+            hidden_states = hidden_states * (_keep.to(hidden_states.dtype) / (1.0 - self.dropout.p))
+        else:
+            hidden_states = self.dropout(hidden_states)
+        return self.LayerNorm(hidden_states + input_tensor)
+
+
+class AttackRTransformerLayer(nn.Module):
+    """recbole/model/layers.py:859-951 with the attention core as one HIP launch."""
+
+    def __init__(self, n_heads, hidden_size, intermediate_size, hidden_dropout_prob, attn_dropout_prob, hidden_act,
+                 layer_norm_eps, combine_option='fixed', use_order=True, use_distance=True, two_level=True,
+                 rich_calibrated_combine='fixed', seq_length=50):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.attack_attention = AttackRMultiHeadAttention(
+            n_heads, hidden_size, hidden_dropout_prob, attn_dropout_prob, layer_norm_eps,
+            use_order=use_order, use_distance=use_distance)
+        self.two_level = two_level
+        self.rich_calibrated_combine = rich_calibrated_combine
+        if self.rich_calibrated_combine == 'trainable':
+            self.rich_calibrated_combine_ratio = torch.nn.Parameter(torch.FloatTensor([0.5]), requires_grad=True)
+        self.combine_option = combine_option
+        if self.combine_option == 'gate':
+            self.gate = torch.nn.Linear(hidden_size, seq_length)
+        self.combine_ratio = 0.5
+        self.feed_forward = FeedForward(hidden_size, intermediate_size, hidden_dropout_prob, hidden_act, layer_norm_eps)
+        self.anneal_step = 0
+
+    def _config(self) -> AttentionConfig:
+        rate = 1.0
+        if self.combine_option == 'annealing':  # stateful, one tick per forward (layers.py:890-891)
+            rate = math.exp(-self.anneal_step / 100000)
+            self.anneal_step += 1
+        return AttentionConfig(n_heads=self.attack_attention.num_attention_heads, combine_option=self.combine_option,
+                               two_level=self.two_level, rich_calibrated_combine=self.rich_calibrated_combine,
+                               adversarial=True, anneal_rate=rate)
+
+    def forward(self, hidden_states, attention_mask, return_attention_prob=False, return_all_attention_prob=False,
+                _rnd=None):
+        att = self.attack_attention
+        mq, mk, mv, qa, ka = att.project(hidden_states)
+        gate_logits = self.gate(mq) if self.combine_option == 'gate' else None
+        cfg = self._config()
+        core_rnd = None
+        if _rnd is not None:
+            core_rnd = ExplicitRandomness(noise=_rnd.noise, keep_after=getattr(_rnd, "keep_after", None),
+                                          keep_mask=getattr(_rnd, "keep_mask", None),
+                                          keep_before=getattr(_rnd, "keep_before", None))
+        p_drop = att.attn_dropout_prob if (self.training or (core_rnd is not None and core_rnd.keep_after is not None)) else 0.0
+        want_probs = return_all_attention_prob or return_attention_prob
+        ctx_att, ctx_cal, attack_mask, probs = ops.calibrated_attention(
+            mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
+            rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
+        attacked_attention_output = att.output(ctx_att, hidden_states, getattr(_rnd, "keep_out_att", None))
+        calibrated_attention_output = att.output(ctx_cal, hidden_states, getattr(_rnd, "keep_out_cal", None))
+        attacked_feedforward_output = self.feed_forward(attacked_attention_output, getattr(_rnd, "keep_ffn_att", None))
+        calibrated_feedforward_output = self.feed_forward(calibrated_attention_output, getattr(_rnd, "keep_ffn_cal", None))
+        combined_attention_prob = probs.get("calibrated_attention")
+        if return_all_attention_prob:
+            all_attention_prob = {
+                'before_spatial': probs["before_spatial"],
+                'after_spatial': probs["after_spatial"],
+                'perturbed_mask': attack_mask,
+                'perturbed_attention': probs["perturbed_attention"],
+                'calibrated_attention': probs["calibrated_attention"],
+            }
+            return (attacked_feedforward_output, calibrated_feedforward_output, attack_mask, combined_attention_prob,
+                    all_attention_prob)
+        return attacked_feedforward_output, calibrated_feedforward_output, attack_mask, combined_attention_prob
+
+
+class AttackRTransformerEncoder(nn.Module):
+    """recbole/model/layers.py:1070-1131."""
+
+    def __init__(self, n_layers=2, n_heads=2, hidden_size=64, inner_size=256, hidden_dropout_prob=0.5,
+                 attn_dropout_prob=0.5, hidden_act='gelu', layer_norm_eps=1e-12, combine_option='fixed', use_order=True,
+                 use_distance=True, two_level=True, rich_calibrated_combine='fixed', seq_length=50):
+        super().__init__()
+        layer = AttackRTransformerLayer(
+            n_heads, hidden_size, inner_size, hidden_dropout_prob, attn_dropout_prob, hidden_act, layer_norm_eps,
+            combine_option, use_order=use_order, use_distance=use_distance, two_level=two_level,
+            rich_calibrated_combine=rich_calibrated_combine, seq_length=seq_length)
+        self.layer = nn.ModuleList([copy.deepcopy(layer) for _ in range(n_layers)])
+
+    def forward(self, hidden_states, attention_mask, output_all_encoded_layers=True, return_attention_prob=False,
+                return_all_attention_prob=False, _rnds: Optional[List] = None):
+        """attention_mask: the reference's dense additive tensor ([B,1,L,L] / [B,1,1,L]) or an
+        `ops.StructuredMask` (same values, derived in-kernel)."""
+        all_encoder_layers = []
+        attacked_hidden_states = None
+        calibrated_hidden_states = None
+        all_attack_masks = []
+        all_attention_prob = [] if return_attention_prob else None
+        all_probs = [] if return_all_attention_prob else None
+        for layer_idx, layer_module in enumerate(self.layer):
+            rnd = _rnds[layer_idx] if _rnds is not None else None
+            outs = layer_module(hidden_states, attention_mask, return_attention_prob, return_all_attention_prob,
+                                _rnd=rnd)
+            attacked_hidden_states, calibrated_hidden_states, attack_mask, combined_attention_prob = outs[:4]
+            hidden_states = calibrated_hidden_states  # layers.py:1112
+            all_attack_masks.append(attack_mask)
+            if output_all_encoded_layers:
+                all_encoder_layers.append((attacked_hidden_states, calibrated_hidden_states))
+            if return_attention_prob:
+                all_attention_prob.append(combined_attention_prob)
+            if return_all_attention_prob:
+                all_probs.append(outs[4])
+        if not output_all_encoded_layers:
+            all_encoder_layers.append((attacked_hidden_states, calibrated_hidden_states))
+        if return_all_attention_prob:
+            return all_encoder_layers, all_attack_masks, all_probs
+        if return_attention_prob:
+            return all_encoder_layers, all_attack_masks, all_attention_prob
+        return all_encoder_layers, all_attack_masks

@@ -1,0 +1,220 @@
+"""AC-SASRec with the reference's model surface, running on the MI355X-native encoder.
+
+Mirrors recbole/model/abstract_recommender.py:108-143 (SequentialRecommender) and
+recbole/model/sequential_recommender/acsasrec.py:9-164 (ACSASRec): same constructor arguments
+(`config` mapping + `dataset.num(field)`), attribute names, method names, return values and
+state-dict keys.  `config[k]` may be any mapping; missing keys read as None like RecBole's Config
+(recbole/config/configurator.py:405-409).
+"""
+from __future__ import annotations
+
+from enum import Enum
+
+import torch
+from torch import nn
+
+from .layers import AttackRTransformerEncoder
+from .ops import StructuredMask
+
+
+class ModelType(Enum):
+    """recbole/utils/enum_type.py (only the member this path needs)."""
+
+    SEQUENTIAL = 2
+
+
+def _cfg(config, key, default=None):
+    try:
+        val = config[key]
+    except KeyError:
+        val = None
+    return default if val is None else val
+
+
+class SequentialRecommender(nn.Module):
+    """recbole/model/abstract_recommender.py:108-143."""
+
+    type = ModelType.SEQUENTIAL
+
+    def __init__(self, config, dataset):
+        super().__init__()
+        self.USER_ID = _cfg(config, 'USER_ID_FIELD', 'user_id')
+        self.ITEM_ID = _cfg(config, 'ITEM_ID_FIELD', 'item_id')
+        self.ITEM_SEQ = self.ITEM_ID + _cfg(config, 'LIST_SUFFIX', '_list')
+        self.ITEM_SEQ_LEN = _cfg(config, 'ITEM_LIST_LENGTH_FIELD', 'item_length')
+        self.POS_ITEM_ID = self.ITEM_ID
+        self.NEG_ITEM_ID = _cfg(config, 'NEG_PREFIX', 'neg_') + self.ITEM_ID
+        self.max_seq_length = _cfg(config, 'MAX_ITEM_LIST_LENGTH', 50)
+        self.n_items = dataset.num(self.ITEM_ID)
+        self.device = _cfg(config, 'device', 'cuda')
+
+    def gather_indexes(self, output, gather_index):
+        """Gathers the vectors at the specific positions over a minibatch (abstract_recommender.py:130-134)."""
+        gather_index = gather_index.view(-1, 1, 1).expand(-1, -1, output.shape[-1])
+        return output.gather(dim=1, index=gather_index).squeeze(1)
+
+    def get_attention_mask(self, item_seq, bidirectional=False):
+        """Dense additive mask exactly as the reference builds it (abstract_recommender.py:136-143)."""
+        attention_mask = (item_seq != 0)
+        extended_attention_mask = attention_mask.unsqueeze(1).unsqueeze(2)
+        if not bidirectional:
+            extended_attention_mask = torch.tril(extended_attention_mask.expand((-1, -1, item_seq.size(-1), -1)))
+        return torch.where(extended_attention_mask, 0., -10000.)
+
+    def get_structured_mask(self, item_seq, bidirectional=False) -> StructuredMask:
+        """Same mask in factored form: 1 byte per key instead of L*L floats per sequence."""
+        return StructuredMask(key_valid=(item_seq != 0).to(torch.uint8), causal=not bidirectional)
+
+
+class ACSASRec(SequentialRecommender):
+    """recbole/model/sequential_recommender/acsasrec.py:9-164."""
+
+    bidirectional = False
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.n_layers = config['n_layers']
+        self.n_heads = config['n_heads']
+        self.hidden_size = config['hidden_size']
+        self.inner_size = config['inner_size']
+        self.hidden_dropout_prob = config['hidden_dropout_prob']
+        self.attn_dropout_prob = config['attn_dropout_prob']
+        self.hidden_act = config['hidden_act']
+        self.layer_norm_eps = config['layer_norm_eps']
+        self.initializer_range = config['initializer_range']
+        self.loss_type = config['loss_type']
+        self.combine_option = config['combine_option']
+        self.rich_calibrated_combine = _cfg(config, 'rich_calibrated_combine')
+        self.two_level = _cfg(config, 'two_level')
+        self.use_position_embedding = _cfg(config, 'use_position_embedding')
+        self.use_order = _cfg(config, 'use_order')
+        self.use_distance = _cfg(config, 'use_distance')
+        self.trainable_mask_loss_weight = _cfg(config, 'trainable_mask_loss_weight')
+        # The reference never forwards seq_length (acsasrec.py:40-54), which pins the gate to L = 50
+        # (layers.py:863,878).  `gate_seq_length` is an opt-in extension for other lengths.
+        seq_length = _cfg(config, 'gate_seq_length', 50)
+
+        self.item_embedding = nn.Embedding(self.n_items, self.hidden_size, padding_idx=0)
+        if self.use_position_embedding:
+            self.position_embedding = nn.Embedding(self.max_seq_length, self.hidden_size)
+        self.trm_encoder = AttackRTransformerEncoder(
+            n_layers=self.n_layers, n_heads=self.n_heads, hidden_size=self.hidden_size, inner_size=self.inner_size,
+            hidden_dropout_prob=self.hidden_dropout_prob, attn_dropout_prob=self.attn_dropout_prob,
+            hidden_act=self.hidden_act, layer_norm_eps=self.layer_norm_eps, combine_option=self.combine_option,
+            use_order=self.use_order, use_distance=self.use_distance, two_level=self.two_level,
+            rich_calibrated_combine=self.rich_calibrated_combine, seq_length=seq_length)
+        self.LayerNorm = nn.LayerNorm(self.hidden_size, eps=self.layer_norm_eps)
+        self.dropout = nn.Dropout(self.hidden_dropout_prob)
+        if self.trainable_mask_loss_weight:
+            self.mask_loss_weight = nn.Parameter(torch.FloatTensor([0.3]), requires_grad=True)
+        else:
+            self.mask_loss_weight = config['mask_loss_weight']
+        if self.loss_type == 'BPR':
+            self.loss_fct = _BPRLoss()
+        elif self.loss_type == 'CE':
+            self.loss_fct = nn.CrossEntropyLoss()
+        else:
+            raise NotImplementedError("Make sure 'loss_type' in ['BPR', 'CE']!")
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        """acsasrec.py:74-84: N(0, initializer_range) weights, zero biases, unit LayerNorm."""
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.initializer_range)
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def forward(self, item_seq, item_seq_len, is_train=False, _rnds=None, _keep_emb=None):
+        item_emb = self.item_embedding(item_seq)
+        input_emb = item_emb
+        if self.use_position_embedding:
+            position_ids = torch.arange(item_seq.size(1), dtype=torch.long, device=item_seq.device)
+            input_emb = item_emb + self.position_embedding(position_ids).unsqueeze(0)
+        input_emb = self.LayerNorm(input_emb)
+        if _keep_emb is not None:
+            input_emb = input_emb * (_keep_emb.to(input_emb.dtype) / (1.0 - self.dropout.p))
+        else:
+            input_emb = self.dropout(input_emb)
+        mask = self.get_structured_mask(item_seq, self.bidirectional)
+        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
+        all_attack_masks = trm_output[1]
+        attacked_output, calibrated_output = trm_output[0][-1]
+        calibrated_output = self.gather_indexes(calibrated_output, item_seq_len - 1)
+        attacked_output = self.gather_indexes(attacked_output, item_seq_len - 1)
+        return attacked_output, calibrated_output, all_attack_masks
+
+    def _cal_loss(self, output, interaction, attack_loss=False):
+        pos_items = interaction[self.POS_ITEM_ID]
+        if self.loss_type == 'BPR':
+            neg_items = interaction[self.NEG_ITEM_ID]
+            pos_score = torch.sum(output * self.item_embedding(pos_items), dim=-1)
+            neg_score = torch.sum(output * self.item_embedding(neg_items), dim=-1)
+            return self.loss_fct(pos_score, neg_score)
+        logits = torch.matmul(output, self.item_embedding.weight.transpose(0, 1))
+        return self.loss_fct(logits, pos_items)
+
+    def calculate_loss(self, interaction, _rnds=None, _keep_emb=None):
+        item_seq = interaction[self.ITEM_SEQ]
+        item_seq_len = interaction[self.ITEM_SEQ_LEN]
+        attacked_output, calibrated_output, all_attack_masks = self.forward(item_seq, item_seq_len, is_train=True,
+                                                                            _rnds=_rnds, _keep_emb=_keep_emb)
+        final_attacked_loss = None
+        if attacked_output is not None:
+            attacked_loss = -self._cal_loss(attacked_output, interaction, attack_loss=True)
+            mask_penalty = [torch.norm(1 - m, p=2) for m in all_attack_masks if m is not None]
+            assert len(mask_penalty) > 0
+            mask_penalty = torch.mean(torch.stack(mask_penalty, dim=0))
+            if self.trainable_mask_loss_weight:
+                final_attacked_loss = attacked_loss + mask_penalty * self.mask_loss_weight[0]
+            else:
+                final_attacked_loss = attacked_loss + mask_penalty * self.mask_loss_weight
+        calibrated_loss = self._cal_loss(calibrated_output, interaction)
+        return final_attacked_loss, calibrated_loss
+
+    def predict(self, interaction):
+        item_seq = interaction[self.ITEM_SEQ]
+        item_seq_len = interaction[self.ITEM_SEQ_LEN]
+        test_item = interaction[self.ITEM_ID]
+        attacked_output, calibrated_output, _ = self.forward(item_seq, item_seq_len)
+        test_item_emb = self.item_embedding(test_item)
+        attacked_scores = torch.mul(attacked_output, test_item_emb).sum(dim=1)
+        scores = torch.mul(calibrated_output, test_item_emb).sum(dim=1)
+        return attacked_scores, scores
+
+    def full_sort_predict(self, interaction, _rnds=None):
+        item_seq = interaction[self.ITEM_SEQ]
+        item_seq_len = interaction[self.ITEM_SEQ_LEN]
+        _, calibrated_output, _ = self.forward(item_seq, item_seq_len, _rnds=_rnds)
+        scores = torch.matmul(calibrated_output, self.item_embedding.weight.transpose(0, 1))
+        return None, scores
+
+
+class _BPRLoss(nn.Module):
+    """recbole/model/loss.py:21-47."""
+
+    def __init__(self, gamma=1e-10):
+        super().__init__()
+        self.gamma = gamma
+
+    def forward(self, pos_score, neg_score):
+        return -torch.log(self.gamma + torch.sigmoid(pos_score - neg_score)).mean()
+
+
+class DictConfig(dict):
+    """Plain-dict stand-in for RecBole's Config: missing keys read as None."""
+
+    def __getitem__(self, k):
+        return self.get(k, None)
+
+
+class ItemCount:
+    """Minimal `dataset` for the model constructors: only `.num(field)` is consulted."""
+
+    def __init__(self, n_items):
+        self.n_items = n_items
+
+    def num(self, field):
+        return self.n_items

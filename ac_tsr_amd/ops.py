@@ -1,0 +1,275 @@
+"""Host side of the fused calibrated-attention operator: tensors in, C-ABI call, tensors out.
+
+`calibrated_attention` is the autograd-aware operator the layer modules call.  It launches
+`acattn_calibrated_attention_fwd` / `_bwd` (include/acattn.h) on torch's current HIP stream with raw
+device pointers; PyTorch only owns the memory.  Inputs must be CUDA(HIP) fp32 tensors -- there is no
+CPU or eager fallback: a CPU tensor or a missing libacattn.so raises.
+
+Reference semantics: recbole/model/layers.py:657-742 (AttackRMultiHeadAttention.cal_attack_mask /
+cal_origin_qkv), :883-936 (AttackRTransformerLayer.combine_attention / forward), :677-680.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BwdIO, FwdOut, Problem
+
+
+@dataclass
+class StructuredMask:
+    """The attention mask of SequentialRecommender.get_attention_mask (abstract_recommender.py:136-143)
+    in factored form: which keys are real items + whether attention is causal.  The kernel derives the
+    additive 0 / -10000 values from it instead of reading a [B,1,L,L] tensor from HBM."""
+
+    key_valid: torch.Tensor  # [B, L] uint8, item_seq != 0
+    causal: bool = True
+
+    def dense(self) -> torch.Tensor:
+        valid = self.key_valid.bool()[:, None, None, :]
+        if self.causal:
+            L = self.key_valid.shape[-1]
+            valid = torch.tril(valid.expand(-1, -1, L, -1))
+        return torch.where(valid, 0.0, -10000.0)
+
+
+@dataclass
+class AttentionConfig:
+    n_heads: int
+    combine_option: str = "gate"  # layers.py:883-896
+    two_level: bool = True  # layers.py:911-914
+    rich_calibrated_combine: str = "fixed"  # layers.py:929-936 (only read when two_level is False)
+    adversarial: bool = True  # False = spatial calibrator only (BASELINE config 2)
+    anneal_rate: float = 1.0
+
+
+@dataclass
+class ExplicitRandomness:
+    """Parity mode: the layer's draws as tensors ([B,h,L,L]); keep masks None = no dropout."""
+
+    noise: Optional[torch.Tensor] = None
+    keep_after: Optional[torch.Tensor] = None
+    keep_mask: Optional[torch.Tensor] = None
+    keep_before: Optional[torch.Tensor] = None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(name: str, t: torch.Tensor, dtype=torch.float32):
+    if not t.is_cuda:
+        raise _lib.AcattnError(
+            f"{name} lives on {t.device}: the calibrated-attention core runs only as HIP kernels on an MI355X "
+            "(no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _fill_problem(q, k, v, qa, ka, gate_logits, mask, w_order, b_order, w_dist, b_dist, scalar, rich_ratio,
+                  cfg: AttentionConfig, p_drop: float, rnd, seed: int, keepalive: list) -> Problem:
+    B, L, H = q.shape
+    prob = Problem()
+    prob.B, prob.L, prob.H, prob.n_heads = B, L, H, cfg.n_heads
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _need_cuda(name, t)
+        assert t.shape == (B, L, H), f"{name} must be [B,L,H]"
+    prob.q, prob.k, prob.v = _ptr(q), _ptr(k), _ptr(v)
+    prob.adversarial = int(cfg.adversarial)
+    if cfg.adversarial:
+        for name, t in (("qa", qa), ("ka", ka)):
+            _need_cuda(name, t)
+            assert t.shape == (B, L, H)
+        prob.qa, prob.ka = _ptr(qa), _ptr(ka)
+    if cfg.combine_option not in _lib.COMBINE:
+        raise KeyError(cfg.combine_option)  # layers.py:894-895
+    prob.combine_option = _lib.COMBINE[cfg.combine_option]
+    if cfg.adversarial and cfg.combine_option == "gate":
+        _need_cuda("gate_logits", gate_logits)
+        if gate_logits.shape != (B, L, L):
+            # same failure as the reference's broadcast at layers.py:888 when seq_length != L
+            raise RuntimeError(f"The size of tensor a ({gate_logits.shape[-1]}) must match the size of tensor b ({L})")
+        prob.gate_logits = _ptr(gate_logits)
+    # mask
+    if isinstance(mask, StructuredMask):
+        kv = mask.key_valid
+        _need_cuda("key_valid", kv, torch.uint8)
+        assert kv.shape == (B, L)
+        prob.mask_mode, prob.causal, prob.key_valid = _lib.MASK_STRUCTURED, int(mask.causal), _ptr(kv)
+    else:
+        _need_cuda("attention_mask", mask)
+        if mask.shape == (B, 1, L, L):
+            prob.mask_mode = _lib.MASK_DENSE_LL
+        elif mask.shape == (B, 1, 1, L):
+            prob.mask_mode = _lib.MASK_DENSE_L
+        else:
+            raise ValueError(f"attention_mask must be [B,1,L,L] or [B,1,1,L], got {tuple(mask.shape)}")
+        prob.mask = _ptr(mask)
+    # spatial calibrator
+    if w_order is not None:
+        for t in (w_order, b_order):
+            _need_cuda("order_affine", t)
+        prob.w_order, prob.b_order = _ptr(w_order), _ptr(b_order)
+    if w_dist is not None:
+        for t in (w_dist, b_dist, scalar):
+            _need_cuda("distance_affine", t)
+        prob.w_dist, prob.b_dist, prob.scalar = _ptr(w_dist), _ptr(b_dist), _ptr(scalar)
+    prob.anneal_rate = float(cfg.anneal_rate)
+    prob.two_level = int(cfg.two_level)
+    if not cfg.two_level:
+        if cfg.rich_calibrated_combine not in ("fixed", "trainable"):
+            raise KeyError(cfg.rich_calibrated_combine)  # layers.py:935-936
+        prob.rich_combine = _lib.RICH[cfg.rich_calibrated_combine]
+        if cfg.rich_calibrated_combine == "trainable":
+            _need_cuda("rich_ratio", rich_ratio)
+            prob.rich_ratio = _ptr(rich_ratio)
+    # randomness
+    prob.p_drop = float(p_drop)
+    if rnd is not None:
+        prob.rng_mode = _lib.RNG_EXPLICIT
+        shape = (B, cfg.n_heads, L, L)
+        if rnd.noise is not None:
+            _need_cuda("noise", rnd.noise)
+            assert rnd.noise.shape == shape
+            prob.noise = _ptr(rnd.noise)
+        for field in ("keep_after", "keep_mask", "keep_before"):
+            t = getattr(rnd, field)
+            if t is not None:
+                if t.dtype != torch.uint8:
+                    t = t.to(torch.uint8)
+                    keepalive.append(t)
+                _need_cuda(field, t, torch.uint8)
+                assert t.shape == shape
+                setattr(prob, field, _ptr(t))
+        if p_drop > 0 and rnd.keep_after is None:
+            prob.p_drop = 0.0
+    else:
+        prob.rng_mode = _lib.RNG_COUNTER
+        prob.seed = seed
+    return prob
+
+
+class _CalibratedAttention(torch.autograd.Function):
+    """Inputs that can carry gradients are the first 12 positional tensors; the rest is configuration."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, mask,
+                cfg: AttentionConfig, p_drop: float, rnd, seed: int, want_probs: bool):
+        lib = _lib.load()
+        B, L, H = q.shape
+        nh = cfg.n_heads
+        keep = []
+        wo = w_order.reshape(-1) if w_order is not None else None
+        wd = w_dist.reshape(-1) if w_dist is not None else None
+        prob = _fill_problem(q, k, v, qa, ka, gate_logits, mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
+                             p_drop, rnd, seed, keep)
+        out = FwdOut()
+        ctx_cal = torch.empty_like(q)
+        out.ctx_calibrated = _ptr(ctx_cal)
+        ctx_att = M = stats = None
+        probs = {}
+        if cfg.adversarial:
+            ctx_att = torch.empty_like(q)
+            M = torch.empty(B, nh, L, L, device=q.device, dtype=torch.float32)
+            stats = torch.empty(B, nh, L, _lib.NSTAT, device=q.device, dtype=torch.float32)
+            out.ctx_attacked, out.attack_mask, out.row_stats = _ptr(ctx_att), _ptr(M), _ptr(stats)
+            if want_probs:
+                for name in ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention"):
+                    probs[name] = torch.empty_like(M)
+                    setattr(out, name, _ptr(probs[name]))
+        _lib.check(lib.acattn_calibrated_attention_fwd(C.byref(prob), C.byref(out), _stream()), "calibrated_attention_fwd")
+        ctx.cfg, ctx.p_drop, ctx.rnd, ctx.seed, ctx.mask = cfg, p_drop, rnd, seed, mask
+        ctx.save_for_backward(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats)
+        outs = [ctx_att, ctx_cal, M] + [probs.get(n) for n in
+                                        ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")]
+        ctx.mark_non_differentiable(*[t for t in outs[3:] if t is not None])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_att, d_cal, d_M, *_unused):
+        # Never mutates saved state: the trainer walks this node twice (retain_graph=True,
+        # recbole/trainer/trainer.py:677,684).
+        (q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats) = ctx.saved_tensors
+        cfg = ctx.cfg
+        if not cfg.adversarial:
+            raise _lib.AcattnError("backward of the spatial-only operator is not provided")
+        lib = _lib.load()
+        B, L, H = q.shape
+        nh, dh = cfg.n_heads, H // cfg.n_heads
+        keep = []
+        wo = w_order.reshape(-1) if w_order is not None else None
+        wd = w_dist.reshape(-1) if w_dist is not None else None
+        prob = _fill_problem(q, k, v, qa, ka, gate_logits, ctx.mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
+                             ctx.p_drop, ctx.rnd, ctx.seed, keep)
+        io = BwdIO()
+        io.attack_mask, io.row_stats = _ptr(M), _ptr(stats)
+        d_att = None if d_att is None else d_att.contiguous()
+        d_cal = None if d_cal is None else d_cal.contiguous()
+        d_M = None if d_M is None else d_M.contiguous()
+        io.d_ctx_attacked, io.d_ctx_calibrated, io.d_attack_mask = _ptr(d_att), _ptr(d_cal), _ptr(d_M)
+        dq, dk, dv, dqa, dka = (torch.empty_like(q) for _ in range(5))
+        io.dq, io.dk, io.dv, io.dqa, io.dka = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqa), _ptr(dka)
+        dgate = None
+        if cfg.combine_option == "gate":
+            dgate = torch.empty_like(gate_logits)
+            io.dgate_logits = _ptr(dgate)
+        dwo = torch.empty(B, nh, 2 * dh, device=q.device, dtype=torch.float32)
+        dwd = torch.empty(B, nh, 2 * dh, device=q.device, dtype=torch.float32)
+        dsm = torch.empty(B, nh, 4, device=q.device, dtype=torch.float32)
+        io.dw_order_part, io.dw_dist_part, io.dsmall_part = _ptr(dwo), _ptr(dwd), _ptr(dsm)
+        _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
+        small = dsm.sum(dim=(0, 1))
+        g_wo = dwo.sum(dim=(0, 1)).view_as(w_order) if w_order is not None else None
+        g_bo = small[0:1].view_as(b_order) if w_order is not None else None
+        g_wd = dwd.sum(dim=(0, 1)).view_as(w_dist) if w_dist is not None else None
+        g_bd = small[1:2].view_as(b_dist) if w_dist is not None else None
+        g_sc = small[2:3].view_as(scalar) if w_dist is not None else None
+        g_rr = small[3:4].view_as(rich_ratio) if rich_ratio is not None else None
+        return (dq, dk, dv, dqa, dka, dgate, g_wo, g_bo, g_wd, g_bd, g_sc, g_rr, None, None, None, None, None, None)
+
+
+def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfig, *, w_order=None, b_order=None,
+                         w_dist=None, b_dist=None, scalar=None, rich_ratio=None, p_drop: float = 0.0,
+                         rnd: Optional[ExplicitRandomness] = None, seed: Optional[int] = None,
+                         want_probs: bool = False):
+    """Fused core of one AttackRTransformerLayer between the projections and the output dense.
+
+    Returns (ctx_attacked [B,L,H] | None, ctx_calibrated [B,L,H], M [B,h,L,L] | None, probs dict).
+    """
+    if rnd is None and seed is None:
+        # one 63-bit seed per call from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    outs = _CalibratedAttention.apply(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar,
+                                      rich_ratio, mask, cfg, p_drop, rnd, seed or 0, want_probs)
+    names = ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")
+    probs = {n: t for n, t in zip(names, outs[3:]) if t is not None}
+    return outs[0], outs[1], outs[2], probs
+
+
+def materialize_randomness(B: int, n_heads: int, L: int, seed: int, p_drop: float, device) -> ExplicitRandomness:
+    """The counter-mode draws for (seed, shape) as tensors (acattn_rng_materialize)."""
+    lib = _lib.load()
+    shape = (B, n_heads, L, L)
+    noise = torch.empty(shape, device=device, dtype=torch.float32)
+    ka, km, kb = (torch.empty(shape, device=device, dtype=torch.uint8) for _ in range(3))
+    _lib.check(lib.acattn_rng_materialize(B, n_heads, L, seed, p_drop, _ptr(noise), _ptr(ka), _ptr(km), _ptr(kb),
+                                          _stream()), "rng_materialize")
+    return ExplicitRandomness(noise=noise, keep_after=ka, keep_mask=km, keep_before=kb)
+
+
+def fwd_algorithmic_bytes(B, L, H, n_heads, adversarial=True, combine_option="gate") -> int:
+    prob = Problem()
+    prob.B, prob.L, prob.H, prob.n_heads = B, L, H, n_heads
+    prob.adversarial, prob.combine_option = int(adversarial), _lib.COMBINE[combine_option]
+    return int(_lib.load().acattn_fwd_algorithmic_bytes(C.byref(prob)))

@@ -1,0 +1,113 @@
+"""The adversarial two-pass training step of AC-SASRec, plus batch data-parallelism.
+
+Mirrors AttackSASRecTrainer._train_epoch (recbole/trainer/trainer.py:631-693): one forward,
+`calibrated_loss.backward(retain_graph=True)` with the attack transforms frozen, then
+`attacked_loss.backward()` with ONLY the attack transforms live, then one optimizer step over all
+parameters.  The reference is single-device (recbole/config/configurator.py:344-348); with
+`parallel.GradSynchronizer` the same step runs as one process per GPU with the batch split across
+ranks and one RCCL all-reduce of the flat gradient buffer between the second backward and the
+optimizer step.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+from torch import optim
+
+
+def is_attack_param(name: str) -> bool:
+    """The trainer selects the attack parameters by substring (trainer.py:672-683): names are load-bearing."""
+    return 'attack_key_transform' in name or 'attack_query_transform' in name
+
+
+class AttackSASRecTrainer:
+    """Minimal trainer: optimizer construction (trainer.py:590-615: Adam by default) and the epoch loop."""
+
+    def __init__(self, config, model, grad_sync=None):
+        self.config = config
+        self.model = model
+        self.learner = (config['learner'] or 'adam') if config is not None else 'adam'
+        self.learning_rate = (config['learning_rate'] or 1e-3) if config is not None else 1e-3
+        self.weight_decay = (config['weight_decay'] or 0.0) if config is not None else 0.0
+        self.device = next(model.parameters()).device
+        self.grad_sync = grad_sync
+        self.optimizer = self._build_optimizer()
+        self._attack = [p for n, p in model.named_parameters() if is_attack_param(n)]
+        self._others = [p for n, p in model.named_parameters() if not is_attack_param(n)]
+
+    def _build_optimizer(self):
+        params = self.model.parameters()
+        learner = self.learner.lower()
+        if learner == 'adam':
+            return optim.Adam(params, lr=self.learning_rate, weight_decay=self.weight_decay)
+        if learner == 'sgd':
+            return optim.SGD(params, lr=self.learning_rate, weight_decay=self.weight_decay)
+        if learner == 'adagrad':
+            return optim.Adagrad(params, lr=self.learning_rate, weight_decay=self.weight_decay)
+        if learner == 'rmsprop':
+            return optim.RMSprop(params, lr=self.learning_rate, weight_decay=self.weight_decay)
+        return optim.Adam(params, lr=self.learning_rate)
+
+    def _check_nan(self, loss):
+        if torch.isnan(loss):
+            raise ValueError('Training loss is nan')  # trainer.py:763-765
+
+    def train_step(self, interaction, check_nan: bool = False):
+        """One batch of trainer.py:660-687.  Returns (attacked_loss, calibrated_loss) as 0-d tensors
+        (no .item(): the caller decides when to synchronise)."""
+        if self.grad_sync is not None:
+            self.grad_sync.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=False)
+        attacked_loss, calibrated_loss = self.model.calculate_loss(interaction)
+        if check_nan:
+            if attacked_loss is not None:
+                self._check_nan(attacked_loss)
+            self._check_nan(calibrated_loss)
+        for p in self._attack:
+            p.requires_grad = False
+        for p in self._others:
+            p.requires_grad = True
+        calibrated_loss.backward(retain_graph=attacked_loss is not None)
+        if attacked_loss is not None:
+            for p in self._attack:
+                p.requires_grad = True
+            for p in self._others:
+                p.requires_grad = False
+            attacked_loss.backward()
+        for p in self._attack:
+            p.requires_grad = True
+        for p in self._others:
+            p.requires_grad = True
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce()
+        self.optimizer.step()
+        return attacked_loss, calibrated_loss
+
+    def _train_epoch(self, train_data: Iterable, epoch_idx: int = 0, attack: bool = True, calibrate: bool = True):
+        assert attack or calibrate
+        self.model.train()
+        total_att: Optional[torch.Tensor] = None
+        total_cal: Optional[torch.Tensor] = None
+        for interaction in train_data:
+            interaction = {k: v.to(self.device) for k, v in interaction.items()} if isinstance(interaction, dict) \
+                else interaction.to(self.device)
+            att, cal = self.train_step(interaction, check_nan=True)
+            if att is not None:
+                total_att = att.detach() if total_att is None else total_att + att.detach()
+            total_cal = cal.detach() if total_cal is None else total_cal + cal.detach()
+        return (0 if total_att is None else total_att.item()), (0 if total_cal is None else total_cal.item())
+
+    @torch.no_grad()
+    def evaluate_scores(self, interaction):
+        """_full_sort_batch_eval (trainer.py:926-945): full-sort logits with the padding item masked out."""
+        self.model.eval()
+        _, scores = self.model.full_sort_predict(interaction)
+        scores = scores.view(-1, self.model.n_items)
+        scores[:, 0] = -float('inf')
+        return scores
+
+
+class ACSASRecTrainer(AttackSASRecTrainer):
+    """Alias kept by the reference (trainer.py:1042-1044)."""

@@ -1,0 +1,154 @@
+/*
+ * acattn.h -- C ABI of the MI355X-native calibrated multi-head self-attention core of AC-TSR.
+ *
+ * The reference (AIM-SE/AC-TSR, a RecBole fork) has no native / FFI boundary: its hot path is a
+ * chain of ATen ops dispatched from Python.  This header defines the boundary
+ * a maintainer would bind instead: plain pointers + sizes, no torch types.  Every entry point names
+ * the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all tensors fp32, contiguous, row-major, resident in device (HBM) memory of the current HIP
+ *     device; ids / validity flags uint8;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work,
+ *     never synchronise, never allocate (hipGraph-capturable);
+ *   - inputs are borrowed for the duration of the enqueued work and never written;
+ *     outputs are caller-allocated;
+ *   - return value 0 = ok; negative = argument error (nothing enqueued), see acattn_last_error();
+ *     positive = hipError_t from the launch.
+ *
+ * Shapes: B batch, L sequence length, H hidden size, nh heads, dh = H / nh.
+ * Supported: dh in {16, 32, 64}, 1 <= L <= 208.
+ */
+#ifndef ACATTN_H_
+#define ACATTN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACATTN_ABI_VERSION 1
+
+/* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
+enum {
+  ACATTN_MASK_STRUCTURED = 0, /* key_valid[B,L] (item_seq != 0) + `causal` flag; 0 / -10000 derived in-kernel */
+  ACATTN_MASK_DENSE_LL = 1,   /* additive mask[B,L,L]  (the reference's [B,1,L,L]) */
+  ACATTN_MASK_DENSE_L = 2     /* additive mask[B,L]    (the reference's [B,1,1,L], AcBERT4Rec acbert4rec.py:173) */
+};
+
+/* combine_option of AttackRTransformerLayer.combine_attention (recbole/model/layers.py:883-896) */
+enum { ACATTN_COMBINE_FIXED = 0, ACATTN_COMBINE_GATE = 1, ACATTN_COMBINE_ANNEALING = 2 };
+
+/* rich_calibrated_combine, used only when two_level == 0 (recbole/model/layers.py:929-936) */
+enum { ACATTN_RICH_NONE = 0, ACATTN_RICH_FIXED = 1, ACATTN_RICH_TRAINABLE = 2 };
+
+/* source of the layer's randomness (recbole/model/layers.py:672,736,917) */
+enum {
+  ACATTN_RNG_EXPLICIT = 0, /* noise / keep masks are read from the tensors below (parity mode) */
+  ACATTN_RNG_COUNTER = 1   /* generated in-kernel from (seed, element index); reproducible, see acattn_rng_materialize */
+};
+
+#define ACATTN_NSTAT 8 /* floats per (b, head, query row) in `row_stats` */
+
+typedef struct acattn_problem {
+  int32_t B, L, H, n_heads;
+  /* projected activations, [B,L,H] each */
+  const float* q;  /* mixed_query_layer  = query(x)                      layers.py:687 */
+  const float* k;  /* mixed_key_layer    = key(x)                        layers.py:688 */
+  const float* v;  /* mixed_value_layer  = value(x)                      layers.py:689 */
+  const float* qa; /* attack_query_transform(mixed_query)  (NULL if !adversarial)   layers.py:658 */
+  const float* ka; /* attack_key_transform(mixed_key)      (NULL if !adversarial)   layers.py:659 */
+  const float* gate_logits; /* gate(mixed_query) BEFORE the sigmoid, [B,L,L]; combine GATE only   layers.py:887 */
+  /* attention mask */
+  int32_t mask_mode;        /* ACATTN_MASK_* */
+  int32_t causal;           /* STRUCTURED only: 1 = tril (SASRec), 0 = bidirectional */
+  const uint8_t* key_valid; /* STRUCTURED: [B,L] */
+  const float* mask;        /* DENSE_*: additive mask */
+  /* spatial calibrator parameters (device pointers; NULL weight = term disabled)  layers.py:636-640 */
+  const float* w_order; /* order_affine.weight    [2*dh] */
+  const float* b_order; /* order_affine.bias      [1]    */
+  const float* w_dist;  /* distance_affine.weight [2*dh] */
+  const float* b_dist;  /* distance_affine.bias   [1]    */
+  const float* scalar;  /* scalar                 [1]    */
+  /* adversarial calibrator options */
+  int32_t adversarial; /* 0 = spatial calibrator only: ctx_calibrated = after_spatial . V, nothing else written */
+  int32_t combine_option; /* ACATTN_COMBINE_* */
+  float anneal_rate;      /* ANNEALING: exp(-step/1e5), computed by the caller (layers.py:890) */
+  int32_t two_level;      /* layers.py:911-914 */
+  int32_t rich_combine;   /* ACATTN_RICH_* (two_level == 0 only) */
+  const float* rich_ratio; /* TRAINABLE: rich_calibrated_combine_ratio [1] */
+  /* randomness */
+  int32_t rng_mode; /* ACATTN_RNG_* */
+  float p_drop;     /* attn_dropout_prob; 0 = no dropout (eval mode) */
+  const float* noise;         /* EXPLICIT: [B,nh,L,L] standard normal draws          layers.py:917 */
+  const uint8_t* keep_after;  /* EXPLICIT: [B,nh,L,L] 0/1 keep mask or NULL           layers.py:736 (after_spatial) */
+  const uint8_t* keep_before; /* EXPLICIT: [B,nh,L,L] or NULL                        layers.py:736 (before_spatial) */
+  const uint8_t* keep_mask;   /* EXPLICIT: [B,nh,L,L] or NULL                        layers.py:672 */
+  uint64_t seed;              /* COUNTER */
+} acattn_problem;
+
+typedef struct acattn_fwd_out {
+  float* ctx_attacked;   /* [B,L,H] head-merged perturbed_attention . V        layers.py:677-680 via :938 */
+  float* ctx_calibrated; /* [B,L,H] head-merged combined attention . V         layers.py:677-680 via :942 */
+  float* attack_mask;    /* [B,nh,L,L] M as returned by the layer (after dropout)  layers.py:915,951 */
+  float* row_stats;      /* [B,nh,L,ACATTN_NSTAT] log-normalisers for the backward, or NULL */
+  /* optional probability dumps, [B,nh,L,L] each, NULL = skip (return_all_attention_prob, layers.py:899-927) */
+  float* after_spatial;
+  float* before_spatial;
+  float* perturbed_attention;
+  float* calibrated_attention;
+} acattn_fwd_out;
+
+typedef struct acattn_bwd_io {
+  /* forward results the backward re-uses */
+  const float* attack_mask; /* [B,nh,L,L] as written by the forward */
+  const float* row_stats;   /* [B,nh,L,ACATTN_NSTAT] */
+  /* cotangents (NULL = zero) */
+  const float* d_ctx_attacked;   /* [B,L,H] */
+  const float* d_ctx_calibrated; /* [B,L,H] */
+  const float* d_attack_mask;    /* [B,nh,L,L] */
+  /* gradients, caller-allocated, fully overwritten */
+  float* dq;  /* [B,L,H] */
+  float* dk;  /* [B,L,H] */
+  float* dv;  /* [B,L,H] */
+  float* dqa; /* [B,L,H] */
+  float* dka; /* [B,L,H] */
+  float* dgate_logits; /* [B,L,L] (combine GATE) or NULL */
+  /* per-(b,head) partial sums of the small parameters; the caller reduces over (B, nh) */
+  float* dw_order_part; /* [B,nh,2*dh] */
+  float* dw_dist_part;  /* [B,nh,2*dh] */
+  float* dsmall_part;   /* [B,nh,4]: d b_order, d b_dist, d scalar, d rich_ratio */
+} acattn_bwd_io;
+
+/* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
+int acattn_abi_version(void);
+
+/* Thread-local description of the last negative return value. */
+const char* acattn_last_error(void);
+
+/* Bytes of algorithmic HBM traffic of one forward call (DESIGN.md "Contract A"/"A'"): what bench.py prices. */
+int64_t acattn_fwd_algorithmic_bytes(const acattn_problem* p);
+
+/*
+ * Fused calibrated attention, forward.  Replaces, for all heads of all sequences in one launch:
+ *   raw scores + spatial calibrator + two softmaxes   recbole/model/layers.py:695-740
+ *   attack-mask scores + softmax                       recbole/model/layers.py:661-672
+ *   noise, perturbed / calibrated / combined probs     recbole/model/layers.py:917-936
+ *   the two P.V products and head merge                recbole/model/layers.py:677-680
+ */
+int acattn_calibrated_attention_fwd(const acattn_problem* p, const acattn_fwd_out* out, void* stream);
+
+/* Backward of the above (what autograd derives for the same op chain in the reference). May be
+ * called any number of times for one forward (the trainer walks the graph twice:
+ * recbole/trainer/trainer.py:677,684). */
+int acattn_calibrated_attention_bwd(const acattn_problem* p, const acattn_bwd_io* io, void* stream);
+
+/* Materialise the COUNTER-mode randomness for (seed, shape) so a run can be replayed in EXPLICIT mode. */
+int acattn_rng_materialize(int32_t B, int32_t n_heads, int32_t L, uint64_t seed, float p_drop, float* noise,
+                           uint8_t* keep_after, uint8_t* keep_mask, uint8_t* keep_before, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACATTN_H_ */

@@ -1,0 +1,116 @@
+"""CPU suite: the C-ABI library builds/loads, exports every declared symbol, and its ctypes mirror
+matches the C layout.  No compute is launched (there is no GPU here); only the argument-validation
+paths, which return before any HIP call, are exercised."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from ac_tsr_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(_lib.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(acattn_[a-z_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert "acattn_calibrated_attention_fwd" in names and "acattn_calibrated_attention_bwd" in names
+    for n in names:
+        assert hasattr(lib, n), f"libacattn.so does not export {n}"
+        assert n in _lib.SYMBOLS, f"ctypes binding lacks {n}"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_abi_version(lib):
+    assert lib.acattn_abi_version() == _lib.ABI_VERSION
+
+
+def test_ctypes_layout_matches_c(tmp_path):
+    """Compile a tiny C program against include/acattn.h and compare sizeof/offsetof with ctypes."""
+    fields = {"acattn_problem": _lib.Problem, "acattn_fwd_out": _lib.FwdOut, "acattn_bwd_io": _lib.BwdIO}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "acattn.h"', 'int main(void){']
+    for cname, cls in fields.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = dict(l.split() for l in out.strip().splitlines())
+    for cname, cls in fields.items():
+        assert int(got[cname]) == C.sizeof(cls)
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_algorithmic_bytes_contracts(lib):
+    from ac_tsr_amd import ops
+    # contract A = 7*T_LH + (1+h)*T_LL, contract A' = 4*T_LH
+    assert ops.fwd_algorithmic_bytes(1, 50, 64, 2) == 119600
+    assert ops.fwd_algorithmic_bytes(512, 50, 64, 2) == 512 * 119600
+    assert ops.fwd_algorithmic_bytes(1, 200, 128, 4) == 1516800
+    assert ops.fwd_algorithmic_bytes(1, 50, 64, 2, adversarial=False) == 51200
+
+
+def test_validation_errors_without_gpu(lib):
+    p, o = _lib.Problem(), _lib.FwdOut()
+    p.B, p.L, p.H, p.n_heads = 2, 50, 64, 3
+    assert lib.acattn_calibrated_attention_fwd(C.byref(p), C.byref(o), None) < 0
+    assert b"not a multiple" in lib.acattn_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+    p.n_heads = 2
+    assert lib.acattn_calibrated_attention_fwd(C.byref(p), C.byref(o), None) < 0
+    assert b"non-NULL" in lib.acattn_last_error()
+    p.L = 500
+    assert lib.acattn_calibrated_attention_fwd(C.byref(p), C.byref(o), None) < 0
+    assert b"sequence length" in lib.acattn_last_error()
+
+
+def test_cpu_tensors_fail_loudly(lib):
+    import torch
+
+    from ac_tsr_amd import AttentionConfig, StructuredMask, calibrated_attention
+    x = torch.zeros(1, 50, 64)
+    with pytest.raises(_lib.AcattnError):
+        calibrated_attention(x, x, x, x, x, torch.zeros(1, 50, 50), StructuredMask(torch.ones(1, 50, dtype=torch.uint8)),
+                             AttentionConfig(n_heads=2))
+
+
+def test_module_surface_matches_reference_state_dict_keys():
+    """State-dict keys and shapes of SURVEY.md section 8b (H=64, h=2, inner=256, L=50)."""
+    from tests._golden import Case
+    import ac_tsr_amd as A
+    c = Case("model_eval")
+    cfg = c.model_cfg()
+    m = A.ACSASRec(A.DictConfig(n_layers=cfg.enc.n_layers, n_heads=cfg.enc.n_heads, hidden_size=cfg.enc.hidden_size,
+                                inner_size=cfg.enc.inner_size, hidden_dropout_prob=0.5, attn_dropout_prob=0.5,
+                                hidden_act='gelu', layer_norm_eps=1e-12, initializer_range=0.02, loss_type='CE',
+                                combine_option='gate', two_level=True, use_order=True, use_distance=True,
+                                rich_calibrated_combine='none', mask_loss_weight=0.03), A.ItemCount(cfg.n_items))
+    ref = c.params()
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(ref)
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    m.load_state_dict(ref)  # a reference checkpoint loads as is
+    attack = [n for n, _ in m.named_parameters() if A.is_attack_param(n)]
+    assert len(attack) == 4 * cfg.enc.n_layers
