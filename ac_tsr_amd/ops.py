@@ -220,15 +220,17 @@ class _CalibratedAttention(torch.autograd.Function):
         io.d_ctx_attacked, io.d_ctx_calibrated, io.d_attack_mask = _ptr(d_att), _ptr(d_cal), _ptr(d_M)
         dq, dk, dv, dqa, dka = (torch.empty_like(q) for _ in range(5))
         io.dq, io.dk, io.dv, io.dqa, io.dka = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqa), _ptr(dka)
-        dgate = None
+        dgate = dgate_part = None
         if cfg.combine_option == "gate":
-            dgate = torch.empty_like(gate_logits)
-            io.dgate_logits = _ptr(dgate)
+            dgate_part = torch.empty(B, nh, L, L, device=q.device, dtype=torch.float32)
+            io.dgate_logits = _ptr(dgate_part)
         dwo = torch.empty(B, nh, 2 * dh, device=q.device, dtype=torch.float32)
         dwd = torch.empty(B, nh, 2 * dh, device=q.device, dtype=torch.float32)
         dsm = torch.empty(B, nh, 4, device=q.device, dtype=torch.float32)
         io.dw_order_part, io.dw_dist_part, io.dsmall_part = _ptr(dwo), _ptr(dwd), _ptr(dsm)
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
+        if dgate_part is not None:
+            dgate = dgate_part.sum(dim=1)  # the gate is shared by the heads (layers.py:887 unsqueeze(1))
         small = dsm.sum(dim=(0, 1))
         g_wo = dwo.sum(dim=(0, 1)).view_as(w_order) if w_order is not None else None
         g_bo = small[0:1].view_as(b_order) if w_order is not None else None

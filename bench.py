@@ -141,7 +141,8 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=6):
 # --------------------------------------------------------------------------------------------------
 def cpu_baseline(a, state_dict, steps):
     from oracle import ac_tsr_ref as O
-    cores = os.cpu_count() or 1
+    # the 1-GPU box exposes every host CPU but grants a 16-CPU share: more threads only oversubscribe
+    cores = min(int(os.environ.get("ACTSR_CPU_THREADS", "16")), os.cpu_count() or 1)
     torch.set_num_threads(cores)
     ecfg = O.EncoderCfg(n_layers=a.layers, n_heads=a.heads, hidden_size=a.hidden, inner_size=a.inner,
                         combine_option="gate", rich_calibrated_combine="none", seq_length=a.seq_len)
@@ -228,7 +229,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    att, cal = (float(x) for x in last)
+    att, cal = (float(x.detach()) for x in last)
     if not (att == att and cal == cal):
         raise SystemExit("Training loss is nan")
 

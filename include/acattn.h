@@ -114,7 +114,7 @@ typedef struct acattn_bwd_io {
   float* dv;  /* [B,L,H] */
   float* dqa; /* [B,L,H] */
   float* dka; /* [B,L,H] */
-  float* dgate_logits; /* [B,L,L] (combine GATE) or NULL */
+  float* dgate_logits; /* [B,nh,L,L] per-head partials of d gate_logits (combine GATE; the caller sums over heads) or NULL */
   /* per-(b,head) partial sums of the small parameters; the caller reduces over (B, nh) */
   float* dw_order_part; /* [B,nh,2*dh] */
   float* dw_dist_part;  /* [B,nh,2*dh] */

@@ -1,0 +1,156 @@
+"""GPU suite (-m gpu): the HIP backward through the C ABI against autograd of the oracle, and the
+model-level two-pass gradients against the reference's golden gradients.
+
+Tolerance: every gradient tensor within 2e-3 of its own max magnitude (fp32; the oracle differentiates
+the materialised formulation, the kernel the rank-1 / log-normaliser formulation)."""
+import types
+
+import pytest
+import torch
+
+import ac_tsr_amd as A
+from oracle import ac_tsr_ref as O
+from tests._golden import Case
+from tests.test_hip_forward import _build_model, _core_kwargs, _project
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BWD_CASES = ["enc_gate_init", "enc_gate_stress", "enc_gate_h4", "enc_fixed_dist", "enc_fixed_order_bidir",
+             "enc_gate_bidir", "enc_plain", "enc_anneal", "enc_leftpad", "enc_L37_ragged", "enc_L200_h4",
+             "enc_L200_d64_bidir"]
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / max(b.abs().max().item(), 1e-12)).item()
+
+
+@pytest.mark.parametrize("name", BWD_CASES)
+@pytest.mark.parametrize("drop", [False, True])
+def test_core_backward_matches_oracle_autograd(name, drop):
+    c = Case(name)
+    cfg, P, mq, mk, mv, qa, ka, gl = _project(c)
+    if drop and name.startswith("enc_L200"):
+        pytest.skip("dropout variant covered at L <= 50")
+    mask = c.t("in.mask")
+    noise = c.t("in.noise.0")
+    g = torch.Generator().manual_seed(11)
+    shape = noise.shape
+    keep_a = torch.empty(shape).bernoulli_(0.5, generator=g) if drop else None
+    keep_m = torch.empty(shape).bernoulli_(0.5, generator=g) if drop else None
+    leaves = {"q": mq, "k": mk, "v": mv, "qa": qa, "ka": ka}
+    if gl is not None:
+        leaves["gl"] = gl
+    dh2 = 2 * cfg.hidden_size // cfg.n_heads
+    zero = torch.zeros(1, dh2)
+    small = {"w_order": P.get("attack_attention.order_affine.weight", zero), "b_order": P.get("attack_attention.order_affine.bias"),
+             "w_dist": P.get("attack_attention.distance_affine.weight", zero), "b_dist": P.get("attack_attention.distance_affine.bias"),
+             "scalar": P.get("attack_attention.scalar")}
+    leaves.update({k: v for k, v in small.items() if v is not None and (k.startswith("w_") is False or True)})
+    cpu = {k: v.detach().clone().requires_grad_(True) for k, v in leaves.items()}
+    ref = O.core_from_projected(cpu["q"], cpu["k"], cpu["v"], cpu["qa"], cpu["ka"], cpu.get("gl"), mask, cpu["w_order"],
+                                cpu.get("b_order"), cpu["w_dist"], cpu.get("b_dist"), cpu.get("scalar"), cfg, noise,
+                                keep_after=keep_a, keep_mask=keep_m)
+    cot = {k: torch.randn(ref[k].shape, generator=g) for k in ("ctx_attacked", "ctx_calibrated", "M")}
+    loss = sum((ref[k] * cot[k]).sum() for k in cot)
+    names = [k for k in cpu]
+    grads = dict(zip(names, torch.autograd.grad(loss, [cpu[k] for k in names], allow_unused=True)))
+
+    dev = {k: v.detach().to(DEV).contiguous().requires_grad_(True) for k, v in leaves.items()}
+    acfg = A.AttentionConfig(n_heads=cfg.n_heads, combine_option=cfg.combine_option, two_level=cfg.two_level,
+                             rich_calibrated_combine=cfg.rich_calibrated_combine)
+    rnd = A.ExplicitRandomness(noise=noise.to(DEV), keep_after=None if keep_a is None else keep_a.to(torch.uint8).to(DEV),
+                               keep_mask=None if keep_m is None else keep_m.to(torch.uint8).to(DEV))
+    kw = {}
+    if cfg.use_order:
+        kw.update(w_order=dev["w_order"], b_order=dev["b_order"])
+    if cfg.use_distance:
+        kw.update(w_dist=dev["w_dist"], b_dist=dev["b_dist"], scalar=dev["scalar"])
+    ctx_a, ctx_c, M, _ = A.calibrated_attention(dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev.get("gl"),
+                                                mask.to(DEV).contiguous(), acfg, p_drop=0.5 if drop else 0.0, rnd=rnd, **kw)
+    dloss = (ctx_a * cot["ctx_attacked"].to(DEV)).sum() + (ctx_c * cot["ctx_calibrated"].to(DEV)).sum() + \
+        (M * cot["M"].to(DEV)).sum()
+    used = [k for k in names if (k in ("q", "k", "v", "qa", "ka", "gl")) or (k in kw)]
+    got = dict(zip(used, torch.autograd.grad(dloss, [dev[k] for k in used], retain_graph=True)))
+    for k in used:
+        if grads[k] is None:
+            continue
+        assert _rel(got[k].cpu(), grads[k]) <= 2e-3, (k, _rel(got[k].cpu(), grads[k]))
+    # second walk over the same graph (recbole/trainer/trainer.py:677,684): identical result
+    again = dict(zip(used, torch.autograd.grad(dloss, [dev[k] for k in used])))
+    for k in used:
+        assert torch.equal(again[k], got[k]) or _rel(again[k], got[k]) <= 1e-5
+
+
+def _rnds_for(c: Case, n_layers, train):
+    out = []
+    for r in c.layer_randomness(n_layers, train):
+        ns = types.SimpleNamespace()
+        for f in ("noise", "keep_after", "keep_before", "keep_mask", "keep_out_att", "keep_out_cal", "keep_ffn_att",
+                  "keep_ffn_cal"):
+            t = getattr(r, f)
+            if t is None:
+                setattr(ns, f, None)
+            elif f == "noise":
+                setattr(ns, f, t.to(DEV))
+            else:
+                setattr(ns, f, t.to(torch.uint8).to(DEV))
+        out.append(ns)
+    return out
+
+
+@pytest.mark.parametrize("name", ["model_eval", "model_eval_stress", "model_train"])
+def test_two_pass_trainer_gradients_match_reference(name):
+    """calculate_loss + the trainer's two backward passes: losses and every parameter gradient against
+    the tensors the genuine reference produced (tests/golden/model_*.npz)."""
+    c = Case(name)
+    cfg, model = _build_model(c)
+    train = bool(int(c.raw["meta.train"]))
+    model.train(train)
+    batch = {k: v.to(DEV) for k, v in c.batch().items()}
+    rnds = _rnds_for(c, cfg.enc.n_layers, train)
+    keep_emb = c.t("in.keep_emb").to(DEV) if train else None
+    model.zero_grad()
+    att, cal = model.calculate_loss(batch, _rnds=rnds, _keep_emb=keep_emb)
+    assert abs(att.item() - float(c.raw["out.att_loss"])) <= 1e-4
+    assert abs(cal.item() - float(c.raw["out.cal_loss"])) <= 1e-4
+    for n, p in model.named_parameters():
+        p.requires_grad = not A.is_attack_param(n)
+    cal.backward(retain_graph=True)
+    for n, p in model.named_parameters():
+        p.requires_grad = A.is_attack_param(n)
+    att.backward()
+    for n, p in model.named_parameters():
+        p.requires_grad = True
+    ref = c.grads()
+    for n, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        # attack_key_transform.bias has a mathematically zero gradient (softmax is invariant to a per-query
+        # shift); both sides hold only ~1e-10 cancellation noise there, hence the absolute floor
+        err = (g.cpu() - ref[n]).abs().max().item()
+        assert err <= 2e-3 * ref[n].abs().max().item() + 2e-8, (n, err, ref[n].abs().max().item())
+
+
+def test_train_step_full_size_is_finite_and_learns():
+    torch.manual_seed(0)
+    cfgd = dict(n_layers=2, n_heads=2, hidden_size=64, inner_size=256, hidden_dropout_prob=0.5, attn_dropout_prob=0.5,
+                hidden_act='gelu', layer_norm_eps=1e-12, initializer_range=0.02, loss_type='CE', combine_option='gate',
+                two_level=True, use_order=True, use_distance=True, mask_loss_weight=0.03)
+    model = A.ACSASRec(A.DictConfig(cfgd), A.ItemCount(5000)).to(DEV)
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), model)
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    B, L = 512, 50
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.randint(1, 5000, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    # learnable toy target: the last item of the sequence
+    target = ids[torch.arange(B), lens - 1]
+    batch = {"item_id_list": ids.to(DEV), "item_length": lens.to(DEV), "item_id": target.to(DEV)}
+    first = last = None
+    for step in range(30):
+        att, cal = trainer.train_step(batch)
+        assert torch.isfinite(att) and torch.isfinite(cal)
+        first = cal.item() if first is None else first
+        last = cal.item()
+    assert last < first - 0.5, (first, last)
+    for n, p in model.named_parameters():
+        assert torch.isfinite(p).all(), n
