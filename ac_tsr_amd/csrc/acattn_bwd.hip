@@ -124,13 +124,20 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
   for (int j = threadIdx.x; j < 2 * DH + 8; j += blockDim.x) s_dwq[j] = 0.f;  // s_dwq and s_small are contiguous
   __syncthreads();
 
-  int first_valid = L;
+  int first_valid = L, last_valid = -1;
   if (structured) {
     for (int j = lane; j < L; j += 64)
-      if (s_km[j] == 0.f) first_valid = min(first_valid, j);
+      if (s_km[j] == 0.f) {
+        first_valid = min(first_valid, j);
+        last_valid = max(last_valid, j);
+      }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) first_valid = min(first_valid, __shfl_xor(first_valid, off));
+    for (int off = 32; off > 0; off >>= 1) {
+      first_valid = min(first_valid, __shfl_xor(first_valid, off));
+      last_valid = max(last_valid, __shfl_xor(last_valid, off));
+    }
   }
+  const int nt_valid = last_valid >= 0 ? (last_valid >> 4) + 1 : nT;  // tiles past the last real item hold no mass
 
   float wo_q[KS], wd_q[KS];
 #pragma unroll
@@ -154,7 +161,8 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
     const int i0 = qb * 16, i = i0 + c;
     const bool row_ok = i < L;
     int nt = nT;
-    if (structured && P.causal && first_valid <= i0) nt = min(nT, qb + 1);
+    if (structured && (P.causal ? first_valid <= i0 : last_valid >= 0))
+      nt = min(P.causal ? min(nT, qb + 1) : nT, nt_valid);
     const size_t prow = (bh * L + (row_ok ? i : 0)) * (size_t)L;
 
     // ---- row fragments: q, qa and the two context cotangents, all in B-operand order ---------------
@@ -309,7 +317,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
           if (use_order) {
             const float pr = fast_sigmoid(ao + co4[r]);
             const float val = (j > i) ? pr : 1.0f - pr;
-            s += __logf(val + ACATTN_LOG_EPS);
+            s += fast_log(val + ACATTN_LOG_EPS);
           }
           if (use_dist) {
             const int dist = i > j ? i - j : j - i;
@@ -318,8 +326,8 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
           }
           const float x = s * inv_sqrt + mk[t][r];
           const float y = tM[t][r] * inv_sqrt + mk[t][r];
-          tS[t][r] = row_ok ? __expf(x - lse_x) : 0.f;  // Pt
-          tM[t][r] = row_ok ? __expf(y - lse_y) : 0.f;  // Mt
+          tS[t][r] = row_ok ? fast_exp(x - lse_x) : 0.f;  // Pt
+          tM[t][r] = row_ok ? fast_exp(y - lse_y) : 0.f;  // Mt
         }
       }
     }
@@ -378,7 +386,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
           for (int r = 0; r < 4; ++r) {
             const float p = tS[t][r] * scaleA(t, r), m = tM[t][r] * scaleM(t, r);
             const float u = (p * m + nz[t][r] * (1.0f - m)) + mk[t][r];
-            const float a = row_ok ? __expf(u - lse_u) : 0.f;
+            const float a = row_ok ? fast_exp(u - lse_u) : 0.f;
             Ap[t][r] = a;
             da += a * dAp[t][r];
           }
@@ -431,12 +439,12 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
           for (int r = 0; r < 4; ++r) {
             const int j = 16 * t + 4 * g + r;
             const float p = tS[t][r] * scaleA(t, r), m = tM[t][r] * scaleM(t, r);
-            const float v_ = p * __expf(1.0f - m) + mk[t][r];
-            const float ac = row_ok ? __expf(v_ - lse_v) : 0.f;
+            const float v_ = p * fast_exp(1.0f - m) + mk[t][r];
+            const float ac = row_ok ? fast_exp(v_ - lse_v) : 0.f;
             Ac[t][r] = ac;
             float ag;
             if (P.combine_option == ACATTN_COMBINE_FIXED) {
-              ag = (j < L && row_ok) ? __expf((p + 0.5f * ac) - lse_f) : 0.f;
+              ag = (j < L && row_ok) ? fast_exp((p + 0.5f * ac) - lse_f) : 0.f;
               gt[t][r] = ag;  // A_g itself is what the inner softmax backward needs
             } else if (P.combine_option == ACATTN_COMBINE_GATE) {
               const float gg = fast_sigmoid(gl[r]);
@@ -445,7 +453,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
             } else {
               ag = rate * p + (1.0f - rate) * ac;
             }
-            const float aw = row_ok ? __expf((ag + mk[t][r]) - lse_w) : 0.f;
+            const float aw = row_ok ? fast_exp((ag + mk[t][r]) - lse_w) : 0.f;
             Aw[t][r] = aw;
             dc += aw * dAw[t][r];
           }
@@ -521,7 +529,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = tS[t][r] * scaleA(t, r), m = tM[t][r] * scaleM(t, r);
-            const float ex1 = __expf(1.0f - m);
+            const float ex1 = fast_exp(1.0f - m);
             const float dv = Ac[t][r] * (dAc[t][r] - r1);
             dPa[t][r] += dv * ex1;
             dMa[t][r] -= dv * (p * ex1);
@@ -585,7 +593,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
             const float pr = fast_sigmoid(ao + co4[r]);
             const float val = (j > i) ? pr : 1.0f - pr;
             const float sgn = (j > i) ? 1.0f : -1.0f;
-            const float d_o = dS * (sgn * pr * (1.0f - pr)) * __frcp_rn(val + ACATTN_LOG_EPS);
+            const float d_o = dS * (sgn * pr * (1.0f - pr)) * fast_rcp(val + ACATTN_LOG_EPS);
             dco[t][r] = d_o;
             da_o += d_o;
           }

@@ -39,7 +39,13 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// Single-instruction transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp) without the denormal
+// range fix-ups of __expf/__logf: every argument here is a softmax exponent, a probability or a sum of
+// probabilities, far from the fp32 range limits; exp of a -10000-masked score flushes to 0 either way.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based randomness (ACATTN_RNG_COUNTER).  One call yields, for the 4 consecutive keys
@@ -64,33 +70,46 @@ struct RngGroup {
 };
 
 // row_id = (b * n_heads + h) * L + i ; grp = j0 / 4.
+// One multiplicative hash of (seed, row, group) seeds a xorshift32 stream; 32-bit integer multiplies run at
+// quarter rate on the VALU, shifts and xors at full rate, so the stream costs ~6 full-rate ops per word.
+__device__ __forceinline__ uint32_t xs32(uint32_t& x) {
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  return x;
+}
+
 __device__ __forceinline__ RngGroup rng_group(uint64_t seed, uint32_t row_id, uint32_t grp, float p_drop) {
   const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
-  const uint32_t base = mix32((row_id * 64u + grp) ^ s_lo) + s_hi;
-  uint32_t w[10];
+  uint32_t x = mix32((row_id * 64u + grp) ^ s_lo) + s_hi;
+  x = x ? x : 0x6C078965u;  // xorshift has the fixed point 0
+  uint32_t w[9];
 #pragma unroll
-  for (int k = 0; k < 10; ++k) w[k] = mix32(base + (uint32_t)(k + 1) * 0x9E3779B9u);
+  for (int k = 0; k < 9; ++k) w[k] = xs32(x);
   RngGroup o;
 #pragma unroll
-  for (int pair = 0; pair < 2; ++pair) {
+  for (int pair = 0; pair < 2; ++pair) {  // Box-Muller, 24-bit uniforms
     const float u1 = (float)((w[2 * pair] >> 8) + 1u) * (1.0f / 16777216.0f);  // (0, 1]
     const float u2 = (float)(w[2 * pair + 1] >> 8) * (1.0f / 16777216.0f);     // [0, 1) revolutions
-    const float rad = __fsqrt_rn(-2.0f * __logf(u1));
+    const float rad = __builtin_amdgcn_sqrtf(-2.0f * fast_log(u1));
     o.n[2 * pair] = rad * __builtin_amdgcn_cosf(u2);
     o.n[2 * pair + 1] = rad * __builtin_amdgcn_sinf(u2);
   }
   const uint32_t thr = (uint32_t)(p_drop * 65536.0f);  // keep iff 16 random bits >= thr
+  // 16-bit fields: keep_after from w4,w5; keep_mask from w6 and the low bytes left over by the uniforms;
+  // keep_before (one-level configs only, dead code elsewhere) from w7,w8
+  const uint32_t fa[4] = {w[4] & 0xFFFFu, w[4] >> 16, w[5] & 0xFFFFu, w[5] >> 16};
+  const uint32_t fm[4] = {w[6] & 0xFFFFu, w[6] >> 16, (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8),
+                          (w[2] & 0xFFu) | ((w[3] & 0xFFu) << 8)};
+  const uint32_t fb[4] = {w[7] & 0xFFFFu, w[7] >> 16, w[8] & 0xFFFFu, w[8] >> 16};
   o.keep_after = 0;
   o.keep_mask = 0;
   o.keep_before = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint32_t ba = (w[4 + (r >> 1)] >> (16 * (r & 1))) & 0xFFFFu;
-    const uint32_t bm = (w[6 + (r >> 1)] >> (16 * (r & 1))) & 0xFFFFu;
-    const uint32_t bb = (w[8 + (r >> 1)] >> (16 * (r & 1))) & 0xFFFFu;
-    o.keep_after |= (ba >= thr ? 1u : 0u) << r;
-    o.keep_mask |= (bm >= thr ? 1u : 0u) << r;
-    o.keep_before |= (bb >= thr ? 1u : 0u) << r;
+    o.keep_after |= (fa[r] >= thr ? 1u : 0u) << r;
+    o.keep_mask |= (fm[r] >= thr ? 1u : 0u) << r;
+    o.keep_before |= (fb[r] >= thr ? 1u : 0u) << r;
   }
   return o;
 }

@@ -15,11 +15,16 @@
 //
 // Reference semantics reproduced (recbole/model/layers.py): :695-740 scores, spatial calibrator and
 // the two first-level softmaxes; :661-672 attack mask; :917-936 adversarial calibrator; :677-680 P.V.
+#include <type_traits>
+
 #include "acattn_common.h"
 
 namespace {
 
-template <int DH, int NT, bool ADV, bool FULL>
+// FAST = the training configuration of every shipped reference config, fixed at compile time:
+// structured causal/bidirectional mask, counter RNG, gate combine, both spatial terms, two_level.
+// Every other combination runs the same code with the flags read at run time.
+template <int DH, int NT, bool ADV, bool FULL, bool FAST>
 __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P, const acattn_fwd_out O) {
   constexpr int KS = DH / 4;   // k-steps of the score MFMAs == floats of a row fragment held per lane
   constexpr int DT = DH / 16;  // 16-wide d tiles of the context
@@ -35,8 +40,9 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
   const size_t rowbase = (size_t)b * L;  // first row of this sequence in a [B*L, H] tensor
   const int hoff = h * DH;
   const size_t bh = (size_t)b * nh + h;
-  const bool structured = P.mask_mode == ACATTN_MASK_STRUCTURED;
-  const bool use_order = P.w_order != nullptr, use_dist = P.w_dist != nullptr;
+  const bool structured = FAST ? true : P.mask_mode == ACATTN_MASK_STRUCTURED;
+  const bool use_order = FAST ? true : P.w_order != nullptr, use_dist = FAST ? true : P.w_dist != nullptr;
+  const int combine_option = FAST ? (int)ACATTN_COMBINE_GATE : P.combine_option;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;            // [LP][VS]
@@ -52,47 +58,63 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     if (row < L) val = *(const f4*)(P.v + (rowbase + row) * H + hoff + 4 * c4);
     *(f4*)(Vs + row * VS + 4 * c4) = val;
   }
-  for (int j = threadIdx.x; j < LP; j += blockDim.x) {
-    float co = 0.f, cd = 0.f, km = ACATTN_NEG_INF;
-    if (j < L) {
-      const float* kr = P.k + (rowbase + j) * H + hoff;
-      if (use_order || use_dist) {
+  for (int idx = threadIdx.x; idx < LP * 4; idx += blockDim.x) {
+    // 4 adjacent lanes share one key: each takes a quarter of the head dimension
+    const int j = idx >> 2, part = idx & 3;
+    float co = 0.f, cd = 0.f;
+    if (j < L && (use_order || use_dist)) {
+      const float* kr = P.k + (rowbase + j) * H + hoff + part * (DH / 4);
 #pragma unroll
-        for (int d4 = 0; d4 < DH / 4; ++d4) {
-          const f4 kv = *(const f4*)(kr + 4 * d4);
-          if (use_order) {
-            const f4 w = *(const f4*)(P.w_order + DH + 4 * d4);
-            co += kv.x * w.x + kv.y * w.y + kv.z * w.z + kv.w * w.w;
-          }
-          if (use_dist) {
-            const f4 w = *(const f4*)(P.w_dist + DH + 4 * d4);
-            cd += kv.x * w.x + kv.y * w.y + kv.z * w.z + kv.w * w.w;
-          }
+      for (int d4 = 0; d4 < DH / 16; ++d4) {
+        const f4 kv = *(const f4*)(kr + 4 * d4);
+        if (use_order) {
+          const f4 w = *(const f4*)(P.w_order + DH + part * (DH / 4) + 4 * d4);
+          co += kv.x * w.x + kv.y * w.y + kv.z * w.z + kv.w * w.w;
+        }
+        if (use_dist) {
+          const f4 w = *(const f4*)(P.w_dist + DH + part * (DH / 4) + 4 * d4);
+          cd += kv.x * w.x + kv.y * w.y + kv.z * w.z + kv.w * w.w;
         }
       }
-      if (structured)
-        km = P.key_valid[rowbase + j] ? 0.f : ACATTN_MASK_FILL;
-      else if (P.mask_mode == ACATTN_MASK_DENSE_L)
-        km = P.mask[rowbase + j];
-      else
-        km = 0.f;
     }
-    s_co[j] = co;
-    s_cd[j] = cd;
-    s_km[j] = km;
-    s_lt[j] = logf((float)(j + 1));
+    co += __shfl_xor(co, 1);
+    co += __shfl_xor(co, 2);
+    cd += __shfl_xor(cd, 1);
+    cd += __shfl_xor(cd, 2);
+    if (part == 0) {
+      float km = ACATTN_NEG_INF;
+      if (j < L) {
+        if (structured)
+          km = P.key_valid[rowbase + j] ? 0.f : ACATTN_MASK_FILL;
+        else if (P.mask_mode == ACATTN_MASK_DENSE_L)
+          km = P.mask[rowbase + j];
+        else
+          km = 0.f;
+      }
+      s_co[j] = co;
+      s_cd[j] = cd;
+      s_km[j] = km;
+      s_lt[j] = logf((float)(j + 1));
+    }
   }
   __syncthreads();
 
   // first unmasked key of the sequence (structured masks): rows before it are fully masked and
   // then spread over ALL keys, so causal tile skipping is only legal from that row on.
-  int first_valid = L;
+  int first_valid = L, last_valid = -1;
   if (structured) {
     for (int j = lane; j < L; j += 64)
-      if (s_km[j] == 0.f) first_valid = min(first_valid, j);
+      if (s_km[j] == 0.f) {
+        first_valid = min(first_valid, j);
+        last_valid = max(last_valid, j);
+      }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) first_valid = min(first_valid, __shfl_xor(first_valid, off));
+    for (int off = 32; off > 0; off >>= 1) {
+      first_valid = min(first_valid, __shfl_xor(first_valid, off));
+      last_valid = max(last_valid, __shfl_xor(last_valid, off));
+    }
   }
+  const int nt_valid = last_valid >= 0 ? (last_valid >> 4) + 1 : nT;  // tiles past the last real item hold no mass
 
   // ---- per-lane constants -----------------------------------------------------------------------
   float wo_q[KS], wd_q[KS];
@@ -108,7 +130,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
   const float inv_sqrt = 1.0f / sqrtf((float)DH);
   const bool has_drop = P.p_drop > 0.f;
   const float keep_scale = has_drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
-  const bool counter = P.rng_mode == ACATTN_RNG_COUNTER;
+  const bool counter = FAST ? true : P.rng_mode == ACATTN_RNG_COUNTER;
 
   for (int kk = 0;; ++kk) {
     const int qb = (kk & 1) ? (kk + 1) * NW - 1 - wave : kk * NW + wave;  // zig-zag: balances causal work
@@ -116,8 +138,16 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     const int i0 = qb * 16, i = i0 + c;
     const bool row_ok = i < L;
     int nt = nT;
-    if (structured && P.causal && first_valid <= i0) nt = min(nT, qb + 1);
+    if (structured && (P.causal ? first_valid <= i0 : last_valid >= 0))
+      nt = min(P.causal ? min(nT, qb + 1) : nT, nt_valid);
     const size_t prow = (bh * L + (row_ok ? i : 0)) * (size_t)L;  // row offset into [B,nh,L,L] tensors
+
+    // The block body is instantiated once per number of processed key tiles (NTB = 1..NT) when NT <= 4:
+    // straight-line code with no per-tile branches, so every global load of the block can be issued
+    // before the first MFMA.  NTB == 0 keeps wave-uniform `t < nt` guards (long sequences).
+    auto body = [&](auto ntb_c) {
+    constexpr int NTB = decltype(ntb_c)::value;
+#define TILE_ON(t) (NTB ? ((t) < NTB) : ((t) < nt))
 
     // ---- query fragments and query-side calibrator terms ----------------------------------------
     float qf[KS], qaf[KS];
@@ -151,7 +181,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     float mk[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t < nt) {
+      if (TILE_ON(t)) {
         const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -173,7 +203,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     for (int t = 0; t < NT; ++t) {
       accS[t] = f4{0.f, 0.f, 0.f, 0.f};
       accM[t] = f4{0.f, 0.f, 0.f, 0.f};
-      if (t < nt) {
+      if (TILE_ON(t)) {
         const int j = 16 * t + c;
         const bool kok = j < L;
         const size_t koff = (rowbase + (kok ? j : 0)) * H + hoff + KS * g;
@@ -208,7 +238,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     float mx = ACATTN_NEG_INF, row_shift = ACATTN_NEG_INF;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t < nt) {
+      if (TILE_ON(t)) {
         const f4 co4 = *(const f4*)(s_co + 16 * t + 4 * g);
         const f4 cd4 = *(const f4*)(s_cd + 16 * t + 4 * g);
 #pragma unroll
@@ -218,7 +248,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
           if (use_order) {  // layers.py:715-719
             const float pr = fast_sigmoid(ao + co4[r]);
             const float val = (j > i) ? pr : 1.0f - pr;
-            s += __logf(val + ACATTN_LOG_EPS);
+            s += fast_log(val + ACATTN_LOG_EPS);
           }
           if (use_dist) {  // layers.py:721-727
             const int dist = i > j ? i - j : j - i;
@@ -237,10 +267,10 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     float zx = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t < nt) {
+      if (TILE_ON(t)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __expf(accS[t][r] - mx);
+          const float e = fast_exp(accS[t][r] - mx);
           accS[t][r] = e;
           zx += e;
         }
@@ -250,7 +280,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     float stat[ACATTN_NSTAT];
 #pragma unroll
     for (int s = 0; s < ACATTN_NSTAT; ++s) stat[s] = 0.f;
-    stat[0] = mx + __logf(zx);
+    stat[0] = mx + fast_log(zx);
 
     // randomness of this row block
     float nz[NT][4];
@@ -259,7 +289,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     if (ADV || has_drop) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
           const int j0 = 16 * t + 4 * g;
           uint32_t ka = 0xFu, km_ = 0xFu, kb = 0xFu;
           if (counter) {
@@ -301,11 +331,11 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
     };
 
     {  // P = dropout(softmax)   layers.py:735-736
-      const float rz = __frcp_rn(zx) * keep_scale;
-      const float rz0 = __frcp_rn(zx);
+      const float rz = fast_rcp(zx) * keep_scale;
+      const float rz0 = fast_rcp(zx);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             accS[t][r] = has_drop ? (kept(keepA, keepA2, t, r) ? accS[t][r] * rz : 0.f) : accS[t][r] * rz0;
@@ -337,14 +367,14 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       if (O.after_spatial) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-          if (t < nt) store_seg(O.after_spatial, t, accS[t]);
+          if (TILE_ON(t)) store_seg(O.after_spatial, t, accS[t]);
         zero_skipped(O.after_spatial);
       }
       // before_spatial = dropout(softmax(raw / sqrt(dh) + mask))   layers.py:740
       float mb = ACATTN_NEG_INF;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float x = accB[FULL ? t : 0][r] * inv_sqrt + mk[t][r];
@@ -357,21 +387,21 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       float zb = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = __expf(accB[FULL ? t : 0][r] - mb);
+            const float e = fast_exp(accB[FULL ? t : 0][r] - mb);
             accB[FULL ? t : 0][r] = e;
             zb += e;
           }
         }
       }
       zb = quad_sum(zb);
-      stat[6] = mb + __logf(zb);
-      const float rzb = __frcp_rn(zb);
+      stat[6] = mb + fast_log(zb);
+      const float rzb = fast_rcp(zb);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float pb = accB[FULL ? t : 0][r] * rzb;
@@ -399,7 +429,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       // spatial calibrator only: ctx = after_spatial . V
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float* vp = Vs + (16 * t + 4 * g + r) * VS + c;
@@ -413,7 +443,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       float my = ACATTN_NEG_INF;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float y = accM[t][r] * inv_sqrt + mk[t][r];
@@ -426,22 +456,22 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       float zy = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = __expf(accM[t][r] - my);
+            const float e = fast_exp(accM[t][r] - my);
             accM[t][r] = e;
             zy += e;
           }
         }
       }
       zy = quad_sum(zy);
-      stat[1] = my + __logf(zy);
+      stat[1] = my + fast_log(zy);
       {
-        const float rz = __frcp_rn(zy);
+        const float rz = fast_rcp(zy);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t < nt) {
+          if (TILE_ON(t)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float m = accM[t][r] * rz;
@@ -459,7 +489,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       float mu = ACATTN_NEG_INF;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = accS[t][r], m = accM[t][r];
@@ -473,28 +503,28 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       float zu = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = __expf(eu[t][r] - mu);
+            const float e = fast_exp(eu[t][r] - mu);
             eu[t][r] = e;
             zu += e;
           }
         }
       }
       zu = quad_sum(zu);
-      stat[2] = mu + __logf(zu);
-      const float rzu = __frcp_rn(zu);
+      stat[2] = mu + fast_log(zu);
+      const float rzu = fast_rcp(zu);
       if (FULL && O.perturbed_attention) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-          if (t < nt) store_seg(O.perturbed_attention, t, eu[t] * rzu);
+          if (TILE_ON(t)) store_seg(O.perturbed_attention, t, eu[t] * rzu);
         zero_skipped(O.perturbed_attention);
       }
       // attacked context: (sum_j e_u V_j) / Z_u
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float* vp = Vs + (16 * t + 4 * g + r) * VS + c;
@@ -511,47 +541,47 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       float zv = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v_ = accS[t][r] * __expf(1.0f - accM[t][r]) + mk[t][r];
-            const float e = __expf(v_ - row_shift);  // inputs lie in [0, e] + mask: shift by the row's mask max
+            const float v_ = accS[t][r] * fast_exp(1.0f - accM[t][r]) + mk[t][r];
+            const float e = fast_exp(v_ - row_shift);  // inputs lie in [0, e] + mask: shift by the row's mask max
             ev[t][r] = e;
             zv += e;
           }
         }
       }
       zv = quad_sum(zv);
-      stat[3] = row_shift + __logf(zv);
-      const float rzv = __frcp_rn(zv);
+      stat[3] = row_shift + fast_log(zv);
+      const float rzv = fast_rcp(zv);
 
       // ---- combine (layers.py:883-896) and final softmax (:925) ---------------------------------
       float zf = 0.f;
-      if (P.combine_option == ACATTN_COMBINE_FIXED) {
+      if (combine_option == ACATTN_COMBINE_FIXED) {
         // inner softmax(P + 0.5*A_c) carries NO mask: every existing key takes part, the skipped
         // (all-zero) tiles contribute exp(0) each.
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t < nt) {
+          if (TILE_ON(t)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int j = 16 * t + 4 * g + r;
-              const float e = (j < L) ? __expf(accS[t][r] + 0.5f * (ev[t][r] * rzv)) : 0.f;
+              const float e = (j < L) ? fast_exp(accS[t][r] + 0.5f * (ev[t][r] * rzv)) : 0.f;
               ev[t][r] = e;
               zf += e;
             }
           }
         }
         zf = quad_sum(zf) + (float)(L - min(L, 16 * nt));
-        stat[5] = __logf(zf);
-        const float rzf = __frcp_rn(zf);
+        stat[5] = fast_log(zf);
+        const float rzf = fast_rcp(zf);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-          if (t < nt) ev[t] *= rzf;
-      } else if (P.combine_option == ACATTN_COMBINE_GATE) {
+          if (TILE_ON(t)) ev[t] *= rzf;
+      } else if (combine_option == ACATTN_COMBINE_GATE) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t < nt) {
+          if (TILE_ON(t)) {
             const int j0 = 16 * t + 4 * g;
             f4 gl = {0.f, 0.f, 0.f, 0.f};
             if (row_ok && j0 < L) {
@@ -575,7 +605,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
         const float rate = P.anneal_rate;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (t < nt) {
+          if (TILE_ON(t)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) ev[t][r] = rate * accS[t][r] + (1.0f - rate) * (ev[t][r] * rzv);
           }
@@ -584,29 +614,29 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       float zw = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = __expf((ev[t][r] + mk[t][r]) - row_shift);
+            const float e = fast_exp((ev[t][r] + mk[t][r]) - row_shift);
             ev[t][r] = e;
             zw += e;
           }
         }
       }
       zw = quad_sum(zw);
-      stat[4] = row_shift + __logf(zw);
-      const float rzw = __frcp_rn(zw);
+      stat[4] = row_shift + fast_log(zw);
+      const float rzw = fast_rcp(zw);
       bool normalised = false;
       if (FULL) {
         if (O.calibrated_attention || !P.two_level) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            if (t < nt) ev[t] *= rzw;
+            if (TILE_ON(t)) ev[t] *= rzw;
           normalised = true;
           if (O.calibrated_attention) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-              if (t < nt) store_seg(O.calibrated_attention, t, ev[t]);
+              if (TILE_ON(t)) store_seg(O.calibrated_attention, t, ev[t]);
             zero_skipped(O.calibrated_attention);
           }
         }
@@ -614,7 +644,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
           const float ratio = P.rich_combine == ACATTN_RICH_TRAINABLE ? P.rich_ratio[0] : 0.5f;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            if (t < nt) {
+            if (TILE_ON(t)) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 if (P.rich_combine == ACATTN_RICH_TRAINABLE)
@@ -628,7 +658,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
+        if (TILE_ON(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float* vp = Vs + (16 * t + 4 * g + r) * VS + c;
@@ -659,6 +689,18 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
         *(f4*)(sp + 4) = f4{stat[4], stat[5], stat[6], stat[7]};
       }
     }
+#undef TILE_ON
+    };  // body
+    if constexpr (NT <= 4) {
+      switch (nt) {
+        case 1: body(std::integral_constant<int, 1>{}); break;
+        case 2: body(std::integral_constant<int, NT >= 2 ? 2 : 1>{}); break;
+        case 3: body(std::integral_constant<int, NT >= 3 ? 3 : 1>{}); break;
+        default: body(std::integral_constant<int, NT>{}); break;
+      }
+    } else {
+      body(std::integral_constant<int, 0>{});
+    }
   }
 }
 
@@ -684,16 +726,24 @@ __global__ void acattn_rng_kernel(int B, int nh, int L, uint64_t seed, float p_d
 template <int DH, int NT>
 int launch_nt(const acattn_problem& p, const acattn_fwd_out& o, bool full, hipStream_t stream) {
   const int nT = (p.L + 15) / 16;
-  const int NW = nT <= 4 ? 2 : 4;  // L=50: 4 query blocks -> 2 waves take {0,3} and {1,2}
+  const int NW = nT <= 4 ? nT : 4;  // one wave per 16-row query block while they fit; zig-zag beyond
   const int LP = nT * 16;
   const size_t lds = (size_t)(LP * (DH + 4) + 4 * LP) * sizeof(float);
   const dim3 grid(p.B * p.n_heads), block(64 * NW);
-  if (!p.adversarial)
-    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, false, false>), grid, block, lds, stream, p, o);
-  else if (full)
-    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, true, true>), grid, block, lds, stream, p, o);
-  else
-    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, true, false>), grid, block, lds, stream, p, o);
+  const bool fast = p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order && p.w_dist &&
+                    (!p.adversarial || (p.combine_option == ACATTN_COMBINE_GATE && p.two_level));
+  if (!p.adversarial) {
+    if (fast)
+      hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, false, false, true>), grid, block, lds, stream, p, o);
+    else
+      hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, false, false, false>), grid, block, lds, stream, p, o);
+  } else if (full) {
+    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, true, true, false>), grid, block, lds, stream, p, o);
+  } else if (fast) {
+    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, true, false, true>), grid, block, lds, stream, p, o);
+  } else {
+    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, true, false, false>), grid, block, lds, stream, p, o);
+  }
   return (int)hipGetLastError();
 }
 
@@ -707,7 +757,11 @@ int launch_dh(const acattn_problem& p, const acattn_fwd_out& o, bool full, hipSt
 
 }  // namespace
 
+int acattn_launch_fwd_fast(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
+
 int acattn_launch_fwd(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
+  const int rc_fast = acattn_launch_fwd_fast(p, o, stream);  // training hot path (L <= 64); -100 = not applicable
+  if (rc_fast != -100) return rc_fast;
   const bool full = p.adversarial && (!p.two_level || o.after_spatial || o.before_spatial || o.perturbed_attention ||
                                       o.calibrated_attention);
   switch (p.H / p.n_heads) {

@@ -69,7 +69,8 @@ def model_config(a):
 # --------------------------------------------------------------------------------------------------
 # kernel roofline: direct C-ABI launches on torch's current stream, HIP events around the timed region
 # --------------------------------------------------------------------------------------------------
-def kernel_roofline(a, device, adversarial=True, iters=300, nsets=6):
+def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
+    nsets = nsets or int(os.environ.get("ACTSR_BENCH_NSETS", "6"))  # 6 sets = 372 MB > 256 MiB Infinity Cache
     from ac_tsr_amd import _lib, ops
     lib = _lib.load()
     B, L, H, nh = a.batch, a.seq_len, a.hidden, a.heads

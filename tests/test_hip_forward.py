@@ -267,3 +267,47 @@ def test_error_behaviour_matches_reference():
     x128 = torch.zeros(2, 50, 128, device=DEV)
     with pytest.raises(_lib.AcattnError):  # head size 128 is outside the supported set
         A.calibrated_attention(x128, x128, x128, x128, x128, gl, m, A.AttentionConfig(n_heads=1), seed=1)
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("p_drop", [0.0, 0.5])
+@pytest.mark.parametrize("shape", [(96, 50, 64, 2), (24, 50, 64, 4), (16, 64, 128, 2), (8, 37, 64, 2)])
+def test_fast_training_kernel_equals_general_kernel(causal, p_drop, shape):
+    """The tuned training kernel (counter RNG, gate, structured mask; acattn_fwd_fast.hip) against the general kernel
+    fed the same draws as explicit tensors (itself pinned to the oracle above): contexts and M."""
+    B, L, H, nh = shape
+    g = torch.Generator().manual_seed(7)
+    q, k, v, qa, ka = (torch.randn(B, L, H, generator=g).to(DEV) for _ in range(5))
+    gl = torch.randn(B, L, L, generator=g).to(DEV)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    kv = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8)
+    kv[0] = 1 - kv[0]  # one left-padded sequence: fully masked leading rows
+    kv = kv.to(DEV)
+    w = lambda *s: (0.3 * torch.randn(*s, generator=g)).to(DEV)
+    dh = H // nh
+    kw = dict(w_order=w(1, 2 * dh), b_order=w(1), w_dist=w(1, 2 * dh), b_dist=w(1), scalar=w(1))
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
+    mask = A.StructuredMask(kv, causal=causal)
+    seed = 991
+    fast = A.calibrated_attention(q, k, v, qa, ka, gl, mask, cfg, p_drop=p_drop, seed=seed, **kw)
+    rnd = A.materialize_randomness(B, nh, L, seed, p_drop, DEV)
+    if p_drop == 0.0:
+        rnd = A.ExplicitRandomness(noise=rnd.noise)
+    ref = A.calibrated_attention(q, k, v, qa, ka, gl, mask, cfg, p_drop=p_drop, rnd=rnd, **kw)
+    # Sequence 0 is left-padded: under the causal mask its leading rows have NO unmasked key, every score
+    # then carries the additive -10000 and the softmax sees fp32-quantised inputs (ulp(1e4) ~ 1e-3).  The two
+    # kernels quantise in different domains (natural vs exp2), so those rows agree only to ~1e-3; they are rows
+    # of padding queries whose outputs no consumer reads.  Everything else must agree tightly.
+    sl = slice(1, None)
+    assert (fast[2][sl] - ref[2][sl]).abs().max() <= 5e-6  # M
+    assert (fast[0][sl] - ref[0][sl]).abs().max() <= 5e-5  # ctx_attacked
+    assert (fast[1][sl] - ref[1][sl]).abs().max() <= 5e-5  # ctx_calibrated
+    for a, b_ in zip(fast[:3], ref[:3]):
+        assert (a[0] - b_[0]).abs().max() <= 2e-3
+    # spatial-only flavour
+    scfg = A.AttentionConfig(n_heads=nh, adversarial=False)
+    f2 = A.calibrated_attention(q, k, v, None, None, None, mask, scfg, p_drop=p_drop, seed=seed, **kw)
+    r2 = A.calibrated_attention(q, k, v, None, None, None, mask, scfg, p_drop=p_drop,
+                                rnd=A.ExplicitRandomness(keep_after=rnd.keep_after) if p_drop > 0 else A.ExplicitRandomness(), **kw)
+    assert (f2[1][sl] - r2[1][sl]).abs().max() <= 5e-5
+    assert (f2[1][0] - r2[1][0]).abs().max() <= 2e-3
