@@ -67,6 +67,8 @@ struct RngGroup {
   uint32_t keep_after;  // bit r set = keep
   uint32_t keep_mask;
   uint32_t keep_before;
+  f4 scale_after;  // keep ? keep_scale : 0   (what dropout multiplies by)
+  f4 scale_mask;
 };
 
 // row_id = (b * n_heads + h) * L + i ; grp = j0 / 4.
@@ -79,7 +81,8 @@ __device__ __forceinline__ uint32_t xs32(uint32_t& x) {
   return x;
 }
 
-__device__ __forceinline__ RngGroup rng_group(uint64_t seed, uint32_t row_id, uint32_t grp, float p_drop) {
+__device__ __forceinline__ RngGroup rng_group(uint64_t seed, uint32_t row_id, uint32_t grp, float p_drop,
+                                              float keep_scale = 1.0f) {
   const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
   uint32_t x = mix32((row_id * 64u + grp) ^ s_lo) + s_hi;
   x = x ? x : 0x6C078965u;  // xorshift has the fixed point 0
@@ -110,6 +113,8 @@ __device__ __forceinline__ RngGroup rng_group(uint64_t seed, uint32_t row_id, ui
     o.keep_after |= (fa[r] >= thr ? 1u : 0u) << r;
     o.keep_mask |= (fm[r] >= thr ? 1u : 0u) << r;
     o.keep_before |= (fb[r] >= thr ? 1u : 0u) << r;
+    o.scale_after[r] = fa[r] >= thr ? keep_scale : 0.f;
+    o.scale_mask[r] = fm[r] >= thr ? keep_scale : 0.f;
   }
   return o;
 }

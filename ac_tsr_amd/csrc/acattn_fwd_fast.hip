@@ -18,6 +18,8 @@
 //     re-softmax inputs are probabilities, so the row's mask maximum is a safe shift;
 //   * exponentials run in the exp2 domain (log2(e) folded into the scales), transcendentals are single
 //     v_exp/v_log/v_rcp instructions.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "acattn_common.h"
@@ -30,7 +32,8 @@ constexpr float kLn2 = 0.69314718055994530942f;
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int DH, bool ADV>
-__global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_problem P, const acattn_fwd_out O) {
+__global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_problem P, const acattn_fwd_out O,
+                                                                 const int stagger) {
   constexpr int KS = DH / 4;
   constexpr int DT = DH / 16;
   constexpr int VS = DH + 4;
@@ -47,6 +50,16 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   const size_t rowbase = (size_t)b * L;
   const int hoff = h * DH;
   const size_t bh = (size_t)b * nh + h;
+
+  // Workgroups that share a CU would otherwise run in lockstep (all load, then all compute, then all
+  // store) and leave HBM idle while computing.  The k-th workgroup dealt to a CU (dispatch is round-robin,
+  // so k ~ blockIdx / #CUs; a speed heuristic only) starts k * stagger sleep quanta later, so that its loads
+  // overlap its neighbours' arithmetic.
+  if (stagger > 0) {
+    // HW_REG_HW_ID[3:0] = wave slot inside the SIMD: the k-th workgroup resident on a CU sits in slot ~k
+    const int gen = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3;
+    for (int k = 0; k < gen * stagger; ++k) __builtin_amdgcn_s_sleep(32);
+  }
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;             // [LP][VS]
@@ -80,45 +93,74 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
     }
   }
 
-  // ---- stage K, Ka, V (coalesced 16-byte loads) and derive the key-side calibrator terms --------------
-  for (int idx = threadIdx.x; idx < LP * (DH / 4); idx += blockDim.x) {
+  // ---- staging, step 1: put EVERY global load of the workgroup in flight (one HBM latency, not three) ----
+  constexpr int KV_IT = DH / 16;  // LP * (DH/4) 16-byte chunks over 64*nT threads
+  constexpr int G_IT = 8;         // L * GS/2 8-byte chunks over 64*nT threads, L <= 64
+  f4 r_k[KV_IT], r_ka[KV_IT], r_v[KV_IT];
+#pragma unroll
+  for (int it = 0; it < KV_IT; ++it) {
+    const int idx = threadIdx.x + it * blockDim.x;
     const int row = idx / (DH / 4), c4 = idx - row * (DH / 4);
-    f4 kv = {0.f, 0.f, 0.f, 0.f}, kav = kv, vv = kv;
+    r_k[it] = f4{0.f, 0.f, 0.f, 0.f};
+    r_ka[it] = r_k[it];
+    r_v[it] = r_k[it];
     if (row < L) {
       const size_t o = (rowbase + row) * H + hoff + 4 * c4;
-      kv = *(const f4*)(P.k + o);
-      if (ADV) kav = *(const f4*)(P.ka + o);
-      vv = *(const f4*)(P.v + o);
+      r_k[it] = *(const f4*)(P.k + o);
+      if (ADV) r_ka[it] = *(const f4*)(P.ka + o);
+      r_v[it] = *(const f4*)(P.v + o);
     }
+  }
+  // gate logits [L, L] of this sequence: one contiguous chunk, copied with coalesced 8-byte accesses; inside
+  // the block body they are LDS reads with no HBM latency (and no ordering behind the M stores)
+  const bool g_even = (L & 1) == 0;
+  const int ghalf = GS >> 1, glhalf = L >> 1;
+  float2 r_g[G_IT];
+  if (ADV && g_even) {
+    const float* gsrc = P.gate_logits + rowbase * L;
+#pragma unroll
+    for (int it = 0; it < G_IT; ++it) {
+      const int idx = threadIdx.x + it * blockDim.x;
+      const int row = idx / ghalf, c2 = idx - row * ghalf;
+      r_g[it] = float2{0.f, 0.f};
+      if (row < L && c2 < glhalf) r_g[it] = *(const float2*)(gsrc + row * L + 2 * c2);
+    }
+  }
+  const f4 w_ko = *(const f4*)(P.w_order + DH + 4 * (threadIdx.x % (DH / 4)));  // blockDim % (DH/4) == 0: same c4 every iteration
+  const f4 w_kd = *(const f4*)(P.w_dist + DH + 4 * (threadIdx.x % (DH / 4)));
+  const uint8_t r_valid = (threadIdx.x < L) ? P.key_valid[rowbase + threadIdx.x] : (uint8_t)0;
+
+  // ---- staging, step 2: registers -> LDS; the key halves of the two spatial affines fall out of the pass ----
+#pragma unroll
+  for (int it = 0; it < KV_IT; ++it) {
+    const int idx = threadIdx.x + it * blockDim.x;
+    const int row = idx / (DH / 4), c4 = idx - row * (DH / 4);
+    const f4 kv = r_k[it];
     *(f4*)(Ks + row * VS + 4 * c4) = kv;
-    if (ADV) *(f4*)(Kas + row * VS + 4 * c4) = kav;
-    *(f4*)(Vs + row * VS + 4 * c4) = vv;
-    const f4 wo = *(const f4*)(P.w_order + DH + 4 * c4), wd = *(const f4*)(P.w_dist + DH + 4 * c4);
-    float co = kv.x * wo.x + kv.y * wo.y + kv.z * wo.z + kv.w * wo.w;
-    float cd = kv.x * wd.x + kv.y * wd.y + kv.z * wd.z + kv.w * wd.w;
+    if (ADV) *(f4*)(Kas + row * VS + 4 * c4) = r_ka[it];
+    *(f4*)(Vs + row * VS + 4 * c4) = r_v[it];
+    float co = kv.x * w_ko.x + kv.y * w_ko.y + kv.z * w_ko.z + kv.w * w_ko.w;
+    float cd = kv.x * w_kd.x + kv.y * w_kd.y + kv.z * w_kd.z + kv.w * w_kd.w;
 #pragma unroll
     for (int off = 1; off < DH / 4; off <<= 1) {  // the DH/4 adjacent lanes of one key row
       co += __shfl_xor(co, off);
       cd += __shfl_xor(cd, off);
     }
     if (c4 == 0) {
-      s_co[row] = co;
+      s_co[row] = -kLog2e * co;  // pre-scaled: sigmoid(o) = 1 / (1 + exp2(ao2 + co2))
       s_cd[row] = cd;
     }
   }
   if (ADV) {
-    // gate logits [L, L] of this sequence: one contiguous chunk, copied with coalesced 8-byte accesses;
-    // inside the block body they are then LDS reads with no HBM latency (and no ordering behind M stores)
-    const float* gsrc = P.gate_logits + rowbase * L;
-    if ((L & 1) == 0) {
-      const int half = GS >> 1, lhalf = L >> 1;
-      for (int idx = threadIdx.x; idx < L * half; idx += blockDim.x) {
-        const int row = idx / half, c2 = idx - row * half;
-        float2 v = {0.f, 0.f};
-        if (c2 < lhalf) v = *(const float2*)(gsrc + row * L + 2 * c2);
-        *(float2*)(Gs + row * GS + 2 * c2) = v;
+    if (g_even) {
+#pragma unroll
+      for (int it = 0; it < G_IT; ++it) {
+        const int idx = threadIdx.x + it * blockDim.x;
+        const int row = idx / ghalf, c2 = idx - row * ghalf;
+        if (row < L) *(float2*)(Gs + row * GS + 2 * c2) = r_g[it];
       }
     } else {
+      const float* gsrc = P.gate_logits + rowbase * L;
       for (int idx = threadIdx.x; idx < L * GS; idx += blockDim.x) {
         const int row = idx / GS, col = idx - row * GS;
         Gs[idx] = col < L ? gsrc[row * L + col] : 0.f;
@@ -128,7 +170,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   if (threadIdx.x < LP) {
     const int j = threadIdx.x;
     float km = ACATTN_NEG_INF;
-    if (j < L) km = P.key_valid[rowbase + j] ? 0.f : ACATTN_MASK_FILL * kLog2e;
+    if (j < L) km = r_valid ? 0.f : ACATTN_MASK_FILL * kLog2e;
     s_km[j] = km;
     s_lt[j] = logf((float)(j + 1));
   }
@@ -164,7 +206,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   const float scale2 = inv_sqrt * kLog2e;  // scores -> exp2 domain
   const bool has_drop = P.p_drop > 0.f;
   const float keep_scale = has_drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
-  const size_t prow = (bh * L + (row_ok ? i : 0)) * (size_t)L;
+  const uint32_t prow = ((uint32_t)bh * L + (row_ok ? i : 0)) * (uint32_t)L;  // fits: launcher checks B*nh*L*L < 2^30
   const uint32_t rng_row = (uint32_t)(bh * L + i);
 
   auto store_seg = [&](float* base, int t, const f4 val) {
@@ -178,6 +220,21 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
       for (int r = 0; r < 4; ++r)
         if (j0 + r < L) p[r] = val[r];
     }
+  };
+
+  const float ao2 = -kLog2e * ao;        // order-affine query half, pre-scaled for exp2(-o)
+  const float nc2 = -(hs2 * scale2);     // -(scalar^2 / 2) / sqrt(dh) * log2e
+  // additive mask of key tile t for this lane's 4 keys (exp2 domain); only tiles that reach the causal
+  // diagonal need the per-element select
+  auto mask4 = [&](int t) -> f4 {
+    const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
+    if (causal && (16 * t + 15 > i0)) {
+      f4 m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m[r] = (16 * t + 4 * g + r > i) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
+      return m;
+    }
+    return km4;
   };
 
   auto body = [&](auto ntb_c) {
@@ -205,53 +262,72 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
       tS[t] = aS;
       tM[t] = aM;
     }
+    // All plain arithmetic below is written on 4-wide vectors (the lane's 4 consecutive keys of a tile) so
+    // that it lowers to packed fp32 instructions (v_pk_fma/mul/add_f32: two elements per issue slot);
+    // only the transcendentals and selects are per component.
     float mx = ACATTN_NEG_INF, my = ACATTN_NEG_INF, shl = ACATTN_NEG_INF;
 #pragma unroll
     for (int t = 0; t < NTB; ++t) {
-      const f4 co4 = *(const f4*)(s_co + 16 * t + 4 * g);
+      const f4 co4 = *(const f4*)(s_co + 16 * t + 4 * g);  // -log2e * (k_j . w_order[dh:])
       const f4 cd4 = *(const f4*)(s_cd + 16 * t + 4 * g);
-      const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
+      const f4 mk4 = mask4(t);
+      const bool diag = 16 * t + 15 > i0;  // wave-uniform: the tile holds keys at or after some query of the block
+      const f4 ea = co4 + ao2;
+      f4 val, lt4;
+      const int d0 = i - (16 * t + 4 * g);  // distance of key r is |d0 - r|
+      if (diag) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * t + 4 * g + r;
-        const bool fut = j > i;
-        const float mkl = (causal && fut) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
-        const float pr = fast_rcp(1.0f + ex2(-kLog2e * (ao + co4[r])));
-        const float val = fut ? pr : 1.0f - pr;
-        float s = tS[t][r] + __builtin_amdgcn_logf(val + ACATTN_LOG_EPS) * kLn2;  // layers.py:718-719
-        const int dist = fut ? j - i : i - j;
-        const float df = s_lt[dist] - (ad + cd4[r]);
-        s -= (df * df) * hs2;  // layers.py:726-727
-        const float x = s * scale2 + mkl;
-        const float y = tM[t][r] * scale2 + mkl;
-        tS[t][r] = x;
-        tM[t][r] = y;
-        mx = fmaxf(mx, x);
-        my = fmaxf(my, y);
-        shl = fmaxf(shl, mkl);
+        for (int r = 0; r < 4; ++r) {
+          const float pr = fast_rcp(1.0f + ex2(ea[r]));
+          val[r] = (d0 - r < 0) ? pr : 1.0f - pr;  // layers.py:715-719: key after the query -> log(p), else log(1 - p)
+          const int dist = d0 - r < 0 ? r - d0 : d0 - r;
+          lt4[r] = s_lt[dist];
+        }
+      } else {
+        const float* lp = s_lt + d0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          val[r] = 1.0f - fast_rcp(1.0f + ex2(ea[r]));
+          lt4[r] = lp[-r];
+        }
       }
+      f4 lg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lg[r] = __builtin_amdgcn_logf(val[r] + ACATTN_LOG_EPS);
+      const f4 df = lt4 - (cd4 + ad);                        // layers.py:721-726
+      f4 x = tS[t] * scale2 + mk4;                           // (S + e_o + e_d) / sqrt(dh) + mask, exp2 domain
+      x = lg * inv_sqrt + x;                                 // log2(.) * ln2 * scale2 == log2(.) / sqrt(dh)
+      x = (df * df) * nc2 + x;
+      const f4 y = tM[t] * scale2 + mk4;
+      tS[t] = x;
+      tM[t] = y;
+      mx = fmaxf(mx, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+      if (ADV) my = fmaxf(my, fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])));
+      shl = fmaxf(shl, fmaxf(fmaxf(mk4[0], mk4[1]), fmaxf(mk4[2], mk4[3])));
     }
     mx = quad_max(mx);
     if (ADV) my = quad_max(my);
     shl = quad_max(shl);  // row's mask maximum (exp2 domain): 0, or -10000*log2e for a fully masked row
-    float zx = 0.f, zy = 0.f;
+    f4 zx4 = {0.f, 0.f, 0.f, 0.f}, zy4 = zx4;
 #pragma unroll
     for (int t = 0; t < NTB; ++t) {
+      const f4 dx = tS[t] - mx, dy = tM[t] - my;
+      f4 e, f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = ex2(tS[t][r] - mx);
-        tS[t][r] = e;
-        zx += e;
-        if (ADV) {
-          const float f = ex2(tM[t][r] - my);
-          tM[t][r] = f;
-          zy += f;
-        }
+        e[r] = ex2(dx[r]);
+        if (ADV) f[r] = ex2(dy[r]);
+      }
+      tS[t] = e;
+      zx4 += e;
+      if (ADV) {
+        tM[t] = f;
+        zy4 += f;
       }
     }
-    zx = quad_sum(zx);
-    if (ADV) zy = quad_sum(zy);
-    const float rzx = fast_rcp(zx), rzy = ADV ? fast_rcp(zy) : 0.f;
+    const float zx = quad_sum((zx4[0] + zx4[1]) + (zx4[2] + zx4[3]));
+    const float zy = ADV ? quad_sum((zy4[0] + zy4[1]) + (zy4[2] + zy4[3])) : 1.f;
+    const float rzx = fast_rcp(zx), rzy = fast_rcp(zy);
 
     f4 ca[DT], cc[DT];
 #pragma unroll
@@ -259,7 +335,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
       ca[dt] = f4{0.f, 0.f, 0.f, 0.f};
       cc[dt] = ca[dt];
     }
-    float zu = 0.f, zv = 0.f, zw = 0.f;
+    f4 zu4 = {0.f, 0.f, 0.f, 0.f}, zv4 = zu4, zw4 = zu4;
 
     // ---- pass 2: dropout, M out, perturbed branch into P.V, exp of the calibrated branch ------------------
 #pragma unroll
@@ -267,44 +343,39 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
       // keep one tile's working set live at a time: without the fence the scheduler hoists the RNG and
       // LDS reads of all tiles to the top and the kernel no longer fits 4 waves per SIMD
       __builtin_amdgcn_sched_barrier(0);
-      const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
-      uint32_t ka = 0xFu, km_ = 0xFu;
-      float nz[4] = {0.f, 0.f, 0.f, 0.f};
+      const f4 mb = mask4(t) - shl;
+      f4 sa = {1.f, 1.f, 1.f, 1.f}, sm = sa, nz = {0.f, 0.f, 0.f, 0.f};
       if (ADV || has_drop) {
-        const RngGroup rg = rng_group(P.seed, rng_row, (uint32_t)(4 * t + g), P.p_drop);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nz[r] = rg.n[r];
+        const RngGroup rg = rng_group(P.seed, rng_row, (uint32_t)(4 * t + g), P.p_drop, keep_scale);
+        nz = f4{rg.n[0], rg.n[1], rg.n[2], rg.n[3]};
         if (has_drop) {
-          ka = rg.keep_after;
-          km_ = rg.keep_mask;
+          sa = rg.scale_after;
+          sm = rg.scale_mask;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);  // the RNG's temporaries die here
+      const f4 p = tS[t] * (sa * rzx);  // P = dropout(softmax)   layers.py:735-736
+      tS[t] = p;
       f4 eu;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * t + 4 * g + r;
-        const float mkl = (causal && j > i) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
-        const float p = ((ka >> r) & 1u) ? tS[t][r] * (rzx * keep_scale) : 0.f;  // P   layers.py:735-736
-        tS[t][r] = p;
-        if (ADV) {
-          const float m = ((km_ >> r) & 1u) ? tM[t][r] * (rzy * keep_scale) : 0.f;  // M   layers.py:670-672
-          tM[t][r] = m;
-          const float u = p * m + nz[r] * (1.0f - m);  // layers.py:918
-          eu[r] = ex2(u * kLog2e + (mkl - shl));
-          zu += eu[r];
-        }
-      }
       if (ADV) {
-        store_seg(O.attack_mask, t, tM[t]);
+        const f4 m = tM[t] * (sm * rzy);  // M   layers.py:670-672
+        store_seg(O.attack_mask, t, m);
+        const f4 au = (p * m + nz * (1.0f - m)) * kLog2e + mb;  // layers.py:918-919
+        const f4 a1 = m * (-kLog2e) + kLog2e;                   // exp(1 - M)
+        f4 ex1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = 16 * t + 4 * g + r;
-          const float mkl = (causal && j > i) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
-          const float v_ = tS[t][r] * ex2(kLog2e - tM[t][r] * kLog2e);  // P * exp(1 - M)   layers.py:920
-          const float e = ex2(v_ * kLog2e + (mkl - shl));
-          tM[t][r] = e;  // M is dead from here on: keep the unnormalised A_c in its registers
-          zv += e;
+          eu[r] = ex2(au[r]);
+          ex1[r] = ex2(a1[r]);
         }
+        zu4 += eu;
+        __builtin_amdgcn_sched_barrier(0);
+        const f4 av = (p * ex1) * kLog2e + mb;  // layers.py:920-921
+        f4 ev;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ev[r] = ex2(av[r]);
+        zv4 += ev;
+        tM[t] = ev;  // M is dead from here on: keep the unnormalised A_c in its registers
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -314,33 +385,33 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
           if (ADV)
             ca[dt] = mfma16(vp[16 * dt], eu[r], ca[dt]);
           else
-            cc[dt] = mfma16(vp[16 * dt], tS[t][r], cc[dt]);  // spatial calibrator only: ctx = P.V
+            cc[dt] = mfma16(vp[16 * dt], p[r], cc[dt]);  // spatial calibrator only: ctx = P.V
         }
       }
     }
 
     // ---- pass 3: gate combine, final softmax, calibrated branch into P.V ---------------------------------
+    float zu = 1.f, zv = 1.f, zw = 1.f;
     if (ADV) {
-      zv = quad_sum(zv);
+      zv = quad_sum((zv4[0] + zv4[1]) + (zv4[2] + zv4[3]));
       const float rzv = fast_rcp(zv);
 #pragma unroll
       for (int t = 0; t < NTB; ++t) {
         __builtin_amdgcn_sched_barrier(0);
-        const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
+        const f4 mb = mask4(t) - shl;
         const int j0 = 16 * t + 4 * g;
         // staged logits; key groups past the row end read a clamped (finite) address, their A_g is 0 anyway
         const f4 gl = *(const f4*)(Gs + (row_ok ? i : 0) * GS + min(j0, GS - 4));
+        const f4 eg = gl * (-kLog2e);
+        f4 gt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gt[r] = fast_rcp(1.0f + ex2(eg[r]));  // sigmoid(gate logits)   layers.py:887
+        const f4 acn = tM[t] * rzv;                                      // A_c
+        const f4 aw = (gt * (tS[t] - acn) + acn) * kLog2e + mb;          // layers.py:888, 925
         f4 ew;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = j0 + r;
-          const float mkl = (causal && j > i) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
-          const float gt = fast_rcp(1.0f + ex2(-kLog2e * gl[r]));
-          const float acn = tM[t][r] * rzv;                      // A_c
-          const float ag = gt * (tS[t][r] - acn) + acn;          // layers.py:888
-          ew[r] = ex2(ag * kLog2e + (mkl - shl));                // layers.py:925
-          zw += ew[r];
-        }
+        for (int r = 0; r < 4; ++r) ew[r] = ex2(aw[r]);
+        zw4 += ew;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float* vp = Vs + (16 * t + 4 * g + r) * VS + c;
@@ -348,23 +419,24 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
           for (int dt = 0; dt < DT; ++dt) cc[dt] = mfma16(vp[16 * dt], ew[r], cc[dt]);
         }
       }
-      zu = quad_sum(zu);
-      zw = quad_sum(zw);
+      zu = quad_sum((zu4[0] + zu4[1]) + (zu4[2] + zu4[3]));
+      zw = quad_sum((zw4[0] + zw4[1]) + (zw4[2] + zw4[3]));
       const float rzu = fast_rcp(zu), rzw = fast_rcp(zw);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         ca[dt] *= rzu;
         cc[dt] *= rzw;
       }
-      for (int t = NTB; t < nT; ++t) store_seg(O.attack_mask, t, f4{0.f, 0.f, 0.f, 0.f});  // causally skipped tiles
+      for (int t = NTB; t < nT; ++t) store_seg(O.attack_mask, t, f4{0.f, 0.f, 0.f, 0.f});  // skipped tiles
     }
 
     if (row_ok) {
-      float* oc = O.ctx_calibrated + (rowbase + i) * H + hoff + 4 * g;
+      const uint32_t coff = ((uint32_t)rowbase + i) * H + hoff + 4 * g;  // 32-bit offset from a scalar base
+      float* oc = O.ctx_calibrated + coff;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) *(f4*)(oc + 16 * dt) = cc[dt];
       if (ADV) {
-        float* oa = O.ctx_attacked + (rowbase + i) * H + hoff + 4 * g;
+        float* oa = O.ctx_attacked + coff;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) *(f4*)(oa + 16 * dt) = ca[dt];
         if (O.row_stats && g == 0) {
@@ -391,12 +463,19 @@ template <int DH>
 int launch_fast(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
   const int nT = (p.L + 15) / 16, LP = nT * 16;
   const int GS = (p.L + 3) & ~3;
-  const size_t lds = (size_t)((p.adversarial ? 3 : 2) * LP * (DH + 4) + 4 * LP + (p.adversarial ? p.L * GS : 0)) * sizeof(float);
+  size_t lds = (size_t)((p.adversarial ? 3 : 2) * LP * (DH + 4) + 4 * LP + (p.adversarial ? p.L * GS : 0)) * sizeof(float);
   const dim3 grid(p.B * p.n_heads), block(64 * nT);
+  static const size_t extra = getenv("ACATTN_EXTRA_LDS") ? (size_t)atoi(getenv("ACATTN_EXTRA_LDS")) : 0;  // residency experiments
+  static const int stagger = getenv("ACATTN_STAGGER") ? atoi(getenv("ACATTN_STAGGER")) : 0;
+  lds += extra;
+  if (lds > 64 * 1024) {
+    hipFuncSetAttribute((const void*)acattn_fwd_fast_kernel<DH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)acattn_fwd_fast_kernel<DH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (p.adversarial)
-    hipLaunchKernelGGL((acattn_fwd_fast_kernel<DH, true>), grid, block, lds, stream, p, o);
+    hipLaunchKernelGGL((acattn_fwd_fast_kernel<DH, true>), grid, block, lds, stream, p, o, stagger);
   else
-    hipLaunchKernelGGL((acattn_fwd_fast_kernel<DH, false>), grid, block, lds, stream, p, o);
+    hipLaunchKernelGGL((acattn_fwd_fast_kernel<DH, false>), grid, block, lds, stream, p, o, stagger);
   return (int)hipGetLastError();
 }
 
@@ -404,7 +483,7 @@ int launch_fast(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t st
 
 // Returns -100 when the problem is outside the fast path's domain (the caller then uses the general kernel).
 int acattn_launch_fwd_fast(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
-  const bool ok = p.L <= 64 && p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order &&
+  const bool ok = p.L <= 64 && (int64_t)p.B * p.n_heads * p.L * p.L < (1LL << 30) && (int64_t)p.B * p.L * p.H < (1LL << 30) && p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order &&
                   p.w_dist && (!p.adversarial || (p.combine_option == ACATTN_COMBINE_GATE && p.two_level)) &&
                   !o.after_spatial && !o.before_spatial && !o.perturbed_attention && !o.calibrated_attention;
   if (!ok) return -100;

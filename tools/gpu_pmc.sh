@@ -12,12 +12,13 @@ pass() {
   echo "pass $tag rc=$?"
 }
 pass sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES || exit 1
+pass sq3 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_WAVES || exit 1
 pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_MFMA || exit 1
 pass fetch FETCH_SIZE || exit 1
 pass write WRITE_SIZE GRBM_GUI_ACTIVE || exit 1
 python3 - <<PY
 import csv, glob, collections
-for tag in ("sq1","sq2","fetch","write"):
+for tag in ("sq1","sq2","sq3","fetch","write"):
     files = glob.glob("$R/gpurun_out/$name/%s/**/*counter_collection.csv" % tag, recursive=True)
     if not files:
         print(tag, "no counter file"); continue
