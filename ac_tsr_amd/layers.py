@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .linear import skinny_linear
 from .ops import AttentionConfig, ExplicitRandomness, StructuredMask
 
 
@@ -64,11 +65,11 @@ class AttackRMultiHeadAttention(nn.Module):
 
     def project(self, input_tensor):
         """mixed q/k/v (layers.py:687-689) and the attack transforms of the MIXED q/k (:658-659)."""
-        mq = self.query(input_tensor)
-        mk = self.key(input_tensor)
-        mv = self.value(input_tensor)
-        qa = self.attack_query_transform(mq)
-        ka = self.attack_key_transform(mk)
+        mq = skinny_linear(input_tensor, self.query)
+        mk = skinny_linear(input_tensor, self.key)
+        mv = skinny_linear(input_tensor, self.value)
+        qa = skinny_linear(mq, self.attack_query_transform)
+        ka = skinny_linear(mk, self.attack_key_transform)
         return mq, mk, mv, qa, ka
 
     def calibrator_params(self):
@@ -81,7 +82,7 @@ class AttackRMultiHeadAttention(nn.Module):
 
     def output(self, context_layer, input_tensor, _keep=None):
         """dense -> dropout -> LayerNorm(+residual) of cal_adjusted_outputs (layers.py:681-683)."""
-        hidden_states = self.dense(context_layer)
+        hidden_states = skinny_linear(context_layer, self.dense)
         if _keep is not None:
             hidden_states = hidden_states * (_keep.to(hidden_states.dtype) / (1.0 - self.out_dropout.p))
         else:
@@ -117,7 +118,7 @@ class FeedForward(nn.Module):
         return x * torch.sigmoid(x)
 
     def forward(self, input_tensor, _keep=None):
-        hidden_states = self.dense_2(self.intermediate_act_fn(self.dense_1(input_tensor)))
+        hidden_states = skinny_linear(self.intermediate_act_fn(skinny_linear(input_tensor, self.dense_1)), self.dense_2)
         if _keep is not None:
             hidden_states = hidden_states * (_keep.to(hidden_states.dtype) / (1.0 - self.dropout.p))
         else:
@@ -160,7 +161,7 @@ class AttackRTransformerLayer(nn.Module):
                 _rnd=None):
         att = self.attack_attention
         mq, mk, mv, qa, ka = att.project(hidden_states)
-        gate_logits = self.gate(mq) if self.combine_option == 'gate' else None
+        gate_logits = skinny_linear(mq, self.gate) if self.combine_option == 'gate' else None
         cfg = self._config()
         core_rnd = None
         if _rnd is not None:

@@ -1,0 +1,59 @@
+"""y = x W^T + b for the tall-skinny activations of this model ([B*L, 64..256], B*L = 25,600 at the
+benchmark shape) with a weight gradient that does not fall into a library pothole.
+
+The forward and the input gradient are ordinary GEMMs (hipBLASLt via torch).  The weight gradient
+dW[N,K] = sum_m g[m,n] x[m,k] is a GEMM whose reduction dimension is B*L: on MI355X / ROCm 7.2 hipBLASLt's
+heuristic answers it with a stream-K kernel that takes 110-125 us, rocBLAS takes 25-50 us but is 20x
+slower on the step's one large GEMM (tools/gemm_probe.py, profiles/).  Here the reduction is split into
+S independent slabs, multiplied as ONE batched GEMM ([S, N, M/S] x [S, M/S, K]) and summed -- the textbook
+split-K, expressed with library calls.  Parameters stay ordinary nn.Linear weights (state-dict keys are
+load-bearing, recbole/trainer/trainer.py:672-683).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _split(m: int) -> int:
+    """Number of slabs: the largest divisor of m that is <= 128 and leaves slabs of >= 128 rows."""
+    best = 1
+    for s in range(2, 129):
+        if m % s == 0 and m // s >= 128:
+            best = s
+    return best
+
+
+class _SkinnyLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        g2 = g.reshape(-1, g.shape[-1])
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ weight).view_as(x)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.shape[-1])
+            m = x2.shape[0]
+            s = _split(m)
+            if s > 1:
+                gw = torch.bmm(g2.view(s, m // s, -1).transpose(1, 2), x2.view(s, m // s, -1)).sum(0)
+            else:
+                gw = g2.t() @ x2
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+def skinny_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
+    """layer(x) with the split-K weight gradient.  CPU tensors (module construction, state-dict tests)
+    take the stock path."""
+    if not x.is_cuda or not torch.is_grad_enabled():
+        return layer(x)
+    return _SkinnyLinear.apply(x, layer.weight, layer.bias)

@@ -65,21 +65,13 @@ class AttackSASRecTrainer:
             if attacked_loss is not None:
                 self._check_nan(attacked_loss)
             self._check_nan(calibrated_loss)
-        for p in self._attack:
-            p.requires_grad = False
-        for p in self._others:
-            p.requires_grad = True
-        calibrated_loss.backward(retain_graph=attacked_loss is not None)
+        # The reference freezes the attack transforms for pass 1 and everything else for pass 2 by toggling
+        # requires_grad, then walks the WHOLE graph twice (frozen leaves just drop what reaches them).
+        # `backward(inputs=...)` accumulates into exactly the same leaves with the same values, and lets
+        # autograd skip the branches that only feed frozen leaves (weight-gradient GEMMs, embedding scatter).
+        calibrated_loss.backward(retain_graph=attacked_loss is not None, inputs=self._others)
         if attacked_loss is not None:
-            for p in self._attack:
-                p.requires_grad = True
-            for p in self._others:
-                p.requires_grad = False
-            attacked_loss.backward()
-        for p in self._attack:
-            p.requires_grad = True
-        for p in self._others:
-            p.requires_grad = True
+            attacked_loss.backward(inputs=self._attack)
         if self.grad_sync is not None:
             self.grad_sync.all_reduce()
         self.optimizer.step()

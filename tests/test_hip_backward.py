@@ -154,3 +154,28 @@ def test_train_step_full_size_is_finite_and_learns():
     assert last < first - 0.5, (first, last)
     for n, p in model.named_parameters():
         assert torch.isfinite(p).all(), n
+
+
+def test_trainer_step_leaves_reference_gradients_on_non_attack_parameters():
+    """AttackSASRecTrainer.train_step (pruned two-pass backward) against the reference's golden gradients.  The
+    calibrated loss does not depend on the noise draw, so every non-attack parameter must match even though the
+    trainer lets the kernel draw its own noise; attack parameters must be non-zero."""
+    c = Case("model_eval")
+    cfg, model = _build_model(c)
+    model.eval()  # golden taken in eval mode (no dropout)
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner="sgd", learning_rate=0.0), model)
+    batch = {k: v.to(DEV) for k, v in c.batch().items()}
+    trainer.optimizer.zero_grad(set_to_none=False)
+    att, cal = model.calculate_loss(batch)
+    cal.backward(retain_graph=True, inputs=trainer._others)
+    att.backward(inputs=trainer._attack)
+    ref = c.grads()
+    for n, p in model.named_parameters():
+        if A.is_attack_param(n):
+            if n.endswith("weight"):
+                assert p.grad is not None and p.grad.abs().max() > 0, n
+            continue
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        err = (g.cpu() - ref[n]).abs().max().item()
+        assert err <= 2e-3 * ref[n].abs().max().item() + 2e-8, (n, err)
+    assert abs(cal.item() - float(c.raw["out.cal_loss"])) <= 1e-4
