@@ -129,10 +129,19 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
         best = us if best is None else min(best, us)
     alg = ops.fwd_algorithmic_bytes(B, L, H, nh, adversarial, "gate")
     achieved = alg / (best * 1e-6) / 1e9
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "fwd_pmc_latest.json")
+    if os.path.exists(pmc) and (B, L, H, nh) == (512, 50, 64, 2):
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and shape
+        # (FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 FETCH_SIZE x2 correction applied)
+        k = json.load(open(pmc))["kernels"].get("acattn_fwd_fast_kernel<32,%s>" % ("true" if adversarial else "false"))
+        if k and "hbm_bytes_per_launch_corrected" in k:
+            traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/fwd_pmc_latest.json"
+
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "acattn_fwd_kernel<%d,%d,%s>" % (H // nh, 4 if L <= 64 else (8 if L <= 128 else 13),
-                                                         "adversarial" if adversarial else "spatial_only"),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": ("acattn_fwd_fast_kernel<%d,%s>" % (H // nh, "true" if adversarial else "false")) if L <= 64 else
+                      "acattn_fwd_kernel<%d,%d,...>" % (H // nh, 8 if L <= 128 else 13),
             "contract": "A" if adversarial else "A'", "algorithmic_bytes_per_launch": alg,
             "avg_launch_us": round(best, 2), "launches_timed": iters, "buffer_sets": nsets}
 
