@@ -15,6 +15,27 @@ import torch
 import torch.nn.functional as F
 
 
+# Set by the trainer while the attacked loss is being differentiated (second backward pass): only the attack
+# transforms accumulate there (recbole/trainer/trainer.py:678-684), so every other layer's weight / bias
+# gradient would be computed and thrown away.  A Python autograd.Function cannot see which of its outputs the
+# engine actually needs, hence this explicit switch.
+_ATTACK_PASS_ONLY = False
+
+
+class attack_pass:
+    """Context manager: inside it, only layers tagged `_acattn_attack = True` produce parameter gradients."""
+
+    def __enter__(self):
+        global _ATTACK_PASS_ONLY
+        self._prev = _ATTACK_PASS_ONLY
+        _ATTACK_PASS_ONLY = True
+
+    def __exit__(self, *exc):
+        global _ATTACK_PASS_ONLY
+        _ATTACK_PASS_ONLY = self._prev
+        return False
+
+
 def _split(m: int) -> int:
     """Number of slabs: the largest divisor of m that is <= 128 and leaves slabs of >= 128 rows."""
     best = 1
@@ -26,9 +47,10 @@ def _split(m: int) -> int:
 
 class _SkinnyLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, is_attack):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.is_attack = is_attack
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -38,7 +60,8 @@ class _SkinnyLinear(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         if ctx.needs_input_grad[0]:
             gx = (g2 @ weight).view_as(x)
-        if ctx.needs_input_grad[1]:
+        want_params = ctx.is_attack or not _ATTACK_PASS_ONLY
+        if ctx.needs_input_grad[1] and want_params:
             x2 = x.reshape(-1, x.shape[-1])
             m = x2.shape[0]
             s = _split(m)
@@ -46,9 +69,9 @@ class _SkinnyLinear(torch.autograd.Function):
                 gw = torch.bmm(g2.view(s, m // s, -1).transpose(1, 2), x2.view(s, m // s, -1)).sum(0)
             else:
                 gw = g2.t() @ x2
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and want_params:
             gb = g2.sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def skinny_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
@@ -56,4 +79,4 @@ def skinny_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
     take the stock path."""
     if not x.is_cuda or not torch.is_grad_enabled():
         return layer(x)
-    return _SkinnyLinear.apply(x, layer.weight, layer.bias)
+    return _SkinnyLinear.apply(x, layer.weight, layer.bias, getattr(layer, "_acattn_attack", False))

@@ -15,6 +15,8 @@ from typing import Iterable, Optional
 import torch
 from torch import optim
 
+from .linear import attack_pass
+
 
 def is_attack_param(name: str) -> bool:
     """The trainer selects the attack parameters by substring (trainer.py:672-683): names are load-bearing."""
@@ -33,6 +35,9 @@ class AttackSASRecTrainer:
         self.device = next(model.parameters()).device
         self.grad_sync = grad_sync
         self.optimizer = self._build_optimizer()
+        for name, module in model.named_modules():  # lets the linear layers skip discarded gradients in pass 2
+            if isinstance(module, torch.nn.Linear):
+                module._acattn_attack = is_attack_param(name)
         self._attack = [p for n, p in model.named_parameters() if is_attack_param(n)]
         self._others = [p for n, p in model.named_parameters() if not is_attack_param(n)]
 
@@ -71,7 +76,8 @@ class AttackSASRecTrainer:
         # autograd skip the branches that only feed frozen leaves (weight-gradient GEMMs, embedding scatter).
         calibrated_loss.backward(retain_graph=attacked_loss is not None, inputs=self._others)
         if attacked_loss is not None:
-            attacked_loss.backward(inputs=self._attack)
+            with attack_pass():
+                attacked_loss.backward(inputs=self._attack)
         if self.grad_sync is not None:
             self.grad_sync.all_reduce()
         self.optimizer.step()
