@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   const float keep_scale = has_drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
   const uint32_t prow = ((uint32_t)bh * L + (row_ok ? i : 0)) * (uint32_t)L;  // fits: launcher checks B*nh*L*L < 2^30
   const uint32_t rng_row = (uint32_t)(bh * L + i);
+  const uint64_t seed_eff = P.seed + (P.seed_device ? *P.seed_device : 0ull);
 
   auto store_seg = [&](float* base, int t, const f4 val) {
     const int j0 = 16 * t + 4 * g;
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
       const f4 mb = mask4(t) - shl;
       f4 sa = {1.f, 1.f, 1.f, 1.f}, sm = sa, nz = {0.f, 0.f, 0.f, 0.f};
       if (ADV || has_drop) {
-        const RngGroup rg = rng_group(P.seed, rng_row, (uint32_t)(4 * t + g), P.p_drop, keep_scale);
+        const RngGroup rg = rng_group(seed_eff, rng_row, (uint32_t)(4 * t + g), P.p_drop, keep_scale);
         nz = f4{rg.n[0], rg.n[1], rg.n[2], rg.n[3]};
         if (has_drop) {
           sa = rg.scale_after;

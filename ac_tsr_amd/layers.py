@@ -172,6 +172,7 @@ class AttackRTransformerLayer(nn.Module):
         want_probs = return_all_attention_prob or return_attention_prob
         ctx_att, ctx_cal, attack_mask, probs = ops.calibrated_attention(
             mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
+            seed_tensor=ops.graph_seed_tensor() if core_rnd is None else None,
             rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
         attacked_attention_output = att.output(ctx_att, hidden_states, getattr(_rnd, "keep_out_att", None))
         calibrated_attention_output = att.output(ctx_cal, hidden_states, getattr(_rnd, "keep_out_cal", None))

@@ -80,3 +80,74 @@ def skinny_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
     if not x.is_cuda or not torch.is_grad_enabled():
         return layer(x)
     return _SkinnyLinear.apply(x, layer.weight, layer.bias, getattr(layer, "_acattn_attack", False))
+
+
+class _FullSortScores(torch.autograd.Function):
+    """scores = output @ E^T over the whole catalogue (acsasrec.py:118-119), with the input gradient
+    d_output = d_scores @ E computed as a batched split-K product: its reduction runs over all N items
+    (100k), the same library pothole as the weight gradients above (242 us -> see profiles/)."""
+
+    @staticmethod
+    def forward(ctx, output, table):
+        ctx.save_for_backward(output, table)
+        return output @ table.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        output, table = ctx.saved_tensors
+        g_out = g_tab = None
+        if ctx.needs_input_grad[0]:
+            n = table.shape[0]
+            s = _split(n)
+            if s > 1:
+                b = g.shape[0]
+                g_out = torch.bmm(g.view(b, s, n // s).transpose(0, 1), table.view(s, n // s, -1)).sum(0)
+            else:
+                g_out = g @ table
+        if ctx.needs_input_grad[1] and not _ATTACK_PASS_ONLY:
+            g_tab = g.t() @ output
+        return g_out, g_tab
+
+
+def full_sort_scores(output: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    if not output.is_cuda or not torch.is_grad_enabled():
+        return torch.matmul(output, table.transpose(0, 1))
+    return _FullSortScores.apply(output, table)
+
+
+class _EmbeddingLookup(torch.autograd.Function):
+    """item_embedding(item_seq) (acsasrec.py:87) whose backward scatters with float atomics (index_add_) instead
+    of torch's sort + segmented reduce (0.41 ms per step at B*L = 25,600 lookups; the atomic form is bounded by
+    6.5 MB of atomic traffic).  Row `padding_idx` receives no gradient, like nn.Embedding."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = weight.shape
+        ctx.padding_idx = padding_idx
+        return F.embedding(idx, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        if _ATTACK_PASS_ONLY:
+            return None, None, None
+        n, h = ctx.shape
+        flat = idx.reshape(-1)
+        if ctx.padding_idx is None:
+            gw = g.new_zeros(n, h)
+            gw.index_add_(0, flat, g.reshape(-1, h))
+            return None, gw, None
+        # about half of all lookups hit the padding row: thousands of atomic adds on ONE 256-byte row serialise
+        # (measured 300 us).  Their sum is discarded anyway, so they are scattered over 4096 scratch rows instead.
+        scratch = 4096
+        gw = g.new_zeros(n + scratch, h)
+        spread = n + (torch.arange(flat.numel(), device=flat.device) & (scratch - 1))
+        gw.index_add_(0, torch.where(flat == ctx.padding_idx, spread, flat), g.reshape(-1, h))
+        return None, gw[:n], None
+
+
+def embedding_lookup(idx: torch.Tensor, emb: torch.nn.Embedding) -> torch.Tensor:
+    if not idx.is_cuda or not torch.is_grad_enabled():
+        return emb(idx)
+    return _EmbeddingLookup.apply(idx, emb.weight, emb.padding_idx)

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from .layers import AttackRTransformerEncoder
+from .linear import embedding_lookup, full_sort_scores
 from .ops import StructuredMask
 
 
@@ -128,7 +129,7 @@ class ACSASRec(SequentialRecommender):
             module.bias.data.zero_()
 
     def forward(self, item_seq, item_seq_len, is_train=False, _rnds=None, _keep_emb=None):
-        item_emb = self.item_embedding(item_seq)
+        item_emb = embedding_lookup(item_seq, self.item_embedding)
         input_emb = item_emb
         if self.use_position_embedding:
             position_ids = torch.arange(item_seq.size(1), dtype=torch.long, device=item_seq.device)
@@ -153,7 +154,7 @@ class ACSASRec(SequentialRecommender):
             pos_score = torch.sum(output * self.item_embedding(pos_items), dim=-1)
             neg_score = torch.sum(output * self.item_embedding(neg_items), dim=-1)
             return self.loss_fct(pos_score, neg_score)
-        logits = torch.matmul(output, self.item_embedding.weight.transpose(0, 1))
+        logits = full_sort_scores(output, self.item_embedding.weight)
         return self.loss_fct(logits, pos_items)
 
     def calculate_loss(self, interaction, _rnds=None, _keep_emb=None):

@@ -58,6 +58,19 @@ class ExplicitRandomness:
     keep_before: Optional[torch.Tensor] = None
 
 
+_GRAPH_SEED: Optional[torch.Tensor] = None
+
+
+def set_graph_seed_tensor(t: Optional[torch.Tensor]) -> None:
+    """Device int64[1] step counter that every counter-RNG launch adds to its seed (None = off)."""
+    global _GRAPH_SEED
+    _GRAPH_SEED = t
+
+
+def graph_seed_tensor() -> Optional[torch.Tensor]:
+    return _GRAPH_SEED
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -78,7 +91,7 @@ def _stream() -> C.c_void_p:
 
 
 def _fill_problem(q, k, v, qa, ka, gate_logits, mask, w_order, b_order, w_dist, b_dist, scalar, rich_ratio,
-                  cfg: AttentionConfig, p_drop: float, rnd, seed: int, keepalive: list) -> Problem:
+                  cfg: AttentionConfig, p_drop: float, rnd, seed: int, keepalive: list, seed_tensor=None) -> Problem:
     B, L, H = q.shape
     prob = Problem()
     prob.B, prob.L, prob.H, prob.n_heads = B, L, H, cfg.n_heads
@@ -156,7 +169,10 @@ def _fill_problem(q, k, v, qa, ka, gate_logits, mask, w_order, b_order, w_dist, 
             prob.p_drop = 0.0
     else:
         prob.rng_mode = _lib.RNG_COUNTER
-        prob.seed = seed
+        prob.seed = seed & 0xFFFFFFFFFFFFFFFF
+        if seed_tensor is not None:
+            _need_cuda("seed_tensor", seed_tensor, torch.int64)
+            prob.seed_device = _ptr(seed_tensor)
     return prob
 
 
@@ -165,7 +181,7 @@ class _CalibratedAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, mask,
-                cfg: AttentionConfig, p_drop: float, rnd, seed: int, want_probs: bool):
+                cfg: AttentionConfig, p_drop: float, rnd, seed: int, want_probs: bool, seed_tensor=None):
         lib = _lib.load()
         B, L, H = q.shape
         nh = cfg.n_heads
@@ -173,7 +189,7 @@ class _CalibratedAttention(torch.autograd.Function):
         wo = w_order.reshape(-1) if w_order is not None else None
         wd = w_dist.reshape(-1) if w_dist is not None else None
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
-                             p_drop, rnd, seed, keep)
+                             p_drop, rnd, seed, keep, seed_tensor)
         out = FwdOut()
         ctx_cal = torch.empty_like(q)
         out.ctx_calibrated = _ptr(ctx_cal)
@@ -189,7 +205,7 @@ class _CalibratedAttention(torch.autograd.Function):
                     probs[name] = torch.empty_like(M)
                     setattr(out, name, _ptr(probs[name]))
         _lib.check(lib.acattn_calibrated_attention_fwd(C.byref(prob), C.byref(out), _stream()), "calibrated_attention_fwd")
-        ctx.cfg, ctx.p_drop, ctx.rnd, ctx.seed, ctx.mask = cfg, p_drop, rnd, seed, mask
+        ctx.cfg, ctx.p_drop, ctx.rnd, ctx.seed, ctx.mask, ctx.seed_tensor = cfg, p_drop, rnd, seed, mask, seed_tensor
         ctx.save_for_backward(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats)
         outs = [ctx_att, ctx_cal, M] + [probs.get(n) for n in
                                         ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")]
@@ -211,7 +227,7 @@ class _CalibratedAttention(torch.autograd.Function):
         wo = w_order.reshape(-1) if w_order is not None else None
         wd = w_dist.reshape(-1) if w_dist is not None else None
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, ctx.mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
-                             ctx.p_drop, ctx.rnd, ctx.seed, keep)
+                             ctx.p_drop, ctx.rnd, ctx.seed, keep, ctx.seed_tensor)
         io = BwdIO()
         io.attack_mask, io.row_stats = _ptr(M), _ptr(stats)
         d_att = None if d_att is None else d_att.contiguous()
@@ -238,13 +254,13 @@ class _CalibratedAttention(torch.autograd.Function):
         g_bd = small[1:2].view_as(b_dist) if w_dist is not None else None
         g_sc = small[2:3].view_as(scalar) if w_dist is not None else None
         g_rr = small[3:4].view_as(rich_ratio) if rich_ratio is not None else None
-        return (dq, dk, dv, dqa, dka, dgate, g_wo, g_bo, g_wd, g_bd, g_sc, g_rr, None, None, None, None, None, None)
+        return (dq, dk, dv, dqa, dka, dgate, g_wo, g_bo, g_wd, g_bd, g_sc, g_rr, None, None, None, None, None, None, None)
 
 
 def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfig, *, w_order=None, b_order=None,
                          w_dist=None, b_dist=None, scalar=None, rich_ratio=None, p_drop: float = 0.0,
                          rnd: Optional[ExplicitRandomness] = None, seed: Optional[int] = None,
-                         want_probs: bool = False):
+                         want_probs: bool = False, seed_tensor: Optional[torch.Tensor] = None):
     """Fused core of one AttackRTransformerLayer between the projections and the output dense.
 
     Returns (ctx_attacked [B,L,H] | None, ctx_calibrated [B,L,H], M [B,h,L,L] | None, probs dict).
@@ -252,8 +268,10 @@ def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfi
     if rnd is None and seed is None:
         # one 63-bit seed per call from torch's CPU generator: reproducible under torch.manual_seed, no device sync
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    # seed_tensor (device int64[1]) is added to `seed` inside the kernels: under hipGraph capture `seed` is frozen
+    # into the graph, the tensor is what changes between replays (trainer.enable_graph)
     outs = _CalibratedAttention.apply(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar,
-                                      rich_ratio, mask, cfg, p_drop, rnd, seed or 0, want_probs)
+                                      rich_ratio, mask, cfg, p_drop, rnd, seed or 0, want_probs, seed_tensor)
     names = ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")
     probs = {n: t for n, t in zip(names, outs[3:]) if t is not None}
     return outs[0], outs[1], outs[2], probs

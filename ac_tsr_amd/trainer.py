@@ -15,6 +15,7 @@ from typing import Iterable, Optional
 import torch
 from torch import optim
 
+from . import ops
 from .linear import attack_pass
 
 
@@ -35,6 +36,7 @@ class AttackSASRecTrainer:
         self.device = next(model.parameters()).device
         self.grad_sync = grad_sync
         self.optimizer = self._build_optimizer()
+        self._graph = None
         for name, module in model.named_modules():  # lets the linear layers skip discarded gradients in pass 2
             if isinstance(module, torch.nn.Linear):
                 module._acattn_attack = is_attack_param(name)
@@ -45,7 +47,9 @@ class AttackSASRecTrainer:
         params = self.model.parameters()
         learner = self.learner.lower()
         if learner == 'adam':
-            return optim.Adam(params, lr=self.learning_rate, weight_decay=self.weight_decay)
+            # capturable: the step counter lives on the device, so the whole step can sit inside a hipGraph
+            return optim.Adam(params, lr=self.learning_rate, weight_decay=self.weight_decay,
+                              capturable=self.device.type == 'cuda')
         if learner == 'sgd':
             return optim.SGD(params, lr=self.learning_rate, weight_decay=self.weight_decay)
         if learner == 'adagrad':
@@ -58,9 +62,10 @@ class AttackSASRecTrainer:
         if torch.isnan(loss):
             raise ValueError('Training loss is nan')  # trainer.py:763-765
 
-    def train_step(self, interaction, check_nan: bool = False):
-        """One batch of trainer.py:660-687.  Returns (attacked_loss, calibrated_loss) as 0-d tensors
-        (no .item(): the caller decides when to synchronise)."""
+    def _eager_step(self, interaction, check_nan: bool = False, with_optimizer: bool = True):
+        """One batch of trainer.py:660-687."""
+        if self._seed_t is not None:
+            self._seed_t += 1  # fresh in-kernel randomness on every (replayed) step
         if self.grad_sync is not None:
             self.grad_sync.zero_grad()
         else:
@@ -78,10 +83,56 @@ class AttackSASRecTrainer:
         if attacked_loss is not None:
             with attack_pass():
                 attacked_loss.backward(inputs=self._attack)
-        if self.grad_sync is not None:
-            self.grad_sync.all_reduce()
-        self.optimizer.step()
+        if with_optimizer:
+            if self.grad_sync is not None:
+                self.grad_sync.all_reduce()
+            self.optimizer.step()
         return attacked_loss, calibrated_loss
+
+    _seed_t = None
+
+    def enable_graph(self, example_interaction, warmup: int = 3):
+        """Capture the training step into a hipGraph (about 600 short kernels per step: eager launches are
+        host-bound).  Inputs are copied into static buffers before each replay; the in-kernel RNG adds a device-side
+        step counter to its seeds so every replay draws fresh noise / dropout.  With a gradient synchronizer the
+        graph ends after the second backward and the all-reduce + optimizer step stay eager."""
+        assert self.device.type == 'cuda'
+        self._static_in = {k: v.clone() for k, v in example_interaction.items()}
+        self._seed_t = torch.zeros(1, dtype=torch.int64, device=self.device)
+        ops.set_graph_seed_tensor(self._seed_t)
+        self._graph_has_optimizer = self.grad_sync is None
+        self.model.train()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_step(self._static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = self._eager_step(self._static_in, with_optimizer=self._graph_has_optimizer)
+        self._graph, self._static_out = graph, outs
+        return self
+
+    def train_step(self, interaction, check_nan: bool = False):
+        """One batch.  Returns (attacked_loss, calibrated_loss) as 0-d tensors (no .item(): the caller decides when
+        to synchronise).  In graph mode the returned tensors are static buffers overwritten by the next step."""
+        if self._graph is None:
+            return self._eager_step(interaction, check_nan)
+        for k, buf in self._static_in.items():
+            src = interaction[k]
+            if src.data_ptr() != buf.data_ptr():
+                buf.copy_(src, non_blocking=True)
+        self._graph.replay()
+        if not self._graph_has_optimizer:
+            self.grad_sync.all_reduce()
+            self.optimizer.step()
+        if check_nan:
+            for t in self._static_out:
+                if t is not None:
+                    self._check_nan(t)
+        return self._static_out
 
     def _train_epoch(self, train_data: Iterable, epoch_idx: int = 0, attack: bool = True, calibrate: bool = True):
         assert attack or calibrate

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 1
+#define ACATTN_ABI_VERSION 2
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -86,6 +86,8 @@ typedef struct acattn_problem {
   const uint8_t* keep_before; /* EXPLICIT: [B,nh,L,L] or NULL                        layers.py:736 (before_spatial) */
   const uint8_t* keep_mask;   /* EXPLICIT: [B,nh,L,L] or NULL                        layers.py:672 */
   uint64_t seed;              /* COUNTER */
+  const uint64_t* seed_device; /* COUNTER, optional: *seed_device (device memory) is added to `seed` when the kernel
+                                  starts -- lets a captured hipGraph draw fresh randomness on every replay */
 } acattn_problem;
 
 typedef struct acattn_fwd_out {

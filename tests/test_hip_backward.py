@@ -179,3 +179,29 @@ def test_trainer_step_leaves_reference_gradients_on_non_attack_parameters():
         err = (g.cpu() - ref[n]).abs().max().item()
         assert err <= 2e-3 * ref[n].abs().max().item() + 2e-8, (n, err)
     assert abs(cal.item() - float(c.raw["out.cal_loss"])) <= 1e-4
+
+
+def test_graph_mode_matches_eager_and_redraws_randomness():
+    """trainer.enable_graph: a captured step equals the eager step on the same batch/seed state, successive
+    replays draw different noise, and training still reduces the loss."""
+    torch.manual_seed(0)
+    cfgd = dict(n_layers=2, n_heads=2, hidden_size=64, inner_size=256, hidden_dropout_prob=0.0, attn_dropout_prob=0.5,
+                hidden_act='gelu', layer_norm_eps=1e-12, initializer_range=0.02, loss_type='CE', combine_option='gate',
+                two_level=True, use_order=True, use_distance=True, mask_loss_weight=0.03)
+    g = torch.Generator().manual_seed(1)
+    B, L, N = 128, 50, 3000
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.randint(1, N, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    batch = {"item_id_list": ids.to(DEV), "item_length": lens.to(DEV), "item_id": ids[torch.arange(B), lens - 1].to(DEV)}
+    model = A.ACSASRec(A.DictConfig(cfgd), A.ItemCount(N)).to(DEV)
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), model)
+    trainer.enable_graph(batch)
+    att1, cal1 = (t.clone() for t in trainer.train_step(batch))
+    att2, cal2 = (t.clone() for t in trainer.train_step(batch))
+    assert torch.isfinite(att1) and torch.isfinite(cal1)
+    assert att1.item() != att2.item()  # new noise / dropout draw and updated weights
+    first = cal1.item()
+    for _ in range(40):
+        att, cal = trainer.train_step(batch)
+    assert cal.item() < first - 0.3, (first, cal.item())
+    A.ops.set_graph_seed_tensor(None)
