@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libacattn.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -54,6 +54,10 @@ class BwdIO(C.Structure):
     ]
 
 
+class CeProblem(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("out", _f), ("table", _f), ("target", _f)]
+
+
 # name -> (restype, argtypes); must list every symbol include/acattn.h declares (tests check this)
 SYMBOLS = {
     "acattn_abi_version": (C.c_int, []),
@@ -61,6 +65,9 @@ SYMBOLS = {
     "acattn_fwd_algorithmic_bytes": (C.c_int64, [C.POINTER(Problem)]),
     "acattn_calibrated_attention_fwd": (C.c_int, [C.POINTER(Problem), C.POINTER(FwdOut), C.c_void_p]),
     "acattn_calibrated_attention_bwd": (C.c_int, [C.POINTER(Problem), C.POINTER(BwdIO), C.c_void_p]),
+    "acattn_full_sort_ce_workspace_bytes": (C.c_int64, [C.POINTER(CeProblem)]),
+    "acattn_full_sort_ce_fwd": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, C.c_void_p]),
+    "acattn_full_sort_ce_bwd": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, _f, _f, C.c_void_p]),
     "acattn_rng_materialize": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, _f, _f, _f, _f,
                                          C.c_void_p]),
 }

@@ -1,0 +1,67 @@
+"""Full-catalogue cross-entropy as one fused HIP operator (include/acattn.h: acattn_full_sort_ce_*).
+
+`full_sort_cross_entropy(output, table, target)` == `CrossEntropyLoss()(output @ table.T, target)`
+(recbole/model/sequential_recommender/acsasrec.py:117-120) but the [B, N] logits never exist in HBM:
+forward and backward each sweep the item table once on the matrix cores.  No CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, linear
+from .ops import _need_cuda, _ptr, _stream
+
+
+def _problem(out, table, target) -> _lib.CeProblem:
+    B, H = out.shape
+    p = _lib.CeProblem()
+    p.B, p.N, p.H = B, table.shape[0], H
+    p.out, p.table, p.target = _ptr(out), _ptr(table), _ptr(target)
+    return p
+
+
+class _FullSortCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, table, target):
+        for name, t in (("output", out), ("item table", table)):
+            _need_cuda(name, t)
+        _need_cuda("target", target, torch.int64)
+        assert out.dim() == 2 and table.dim() == 2 and out.shape[1] == table.shape[1] and target.shape == (out.shape[0],)
+        lib = _lib.load()
+        p = _problem(out, table, target)
+        nbytes = lib.acattn_full_sort_ce_workspace_bytes(C.byref(p))
+        if nbytes < 0:
+            raise _lib.AcattnError(f"fused cross-entropy supports hidden sizes 64 and 128, got {out.shape[1]}")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
+        lse = torch.empty(out.shape[0], device=out.device, dtype=torch.float32)
+        row_loss = torch.empty_like(lse)
+        _lib.check(lib.acattn_full_sort_ce_fwd(C.byref(p), _ptr(ws), _ptr(lse), _ptr(row_loss), _stream()), "full_sort_ce_fwd")
+        ctx.save_for_backward(out, table, target, lse)
+        ctx.ws_bytes = nbytes
+        return row_loss
+
+    @staticmethod
+    def backward(ctx, d_row_loss):
+        out, table, target, lse = ctx.saved_tensors
+        lib = _lib.load()
+        p = _problem(out, table, target)
+        ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=out.device)
+        coef = d_row_loss.contiguous()
+        d_out = torch.empty_like(out)
+        # the item table is not an attack parameter: its gradient is dropped in the attacked-loss pass
+        want_table = ctx.needs_input_grad[1] and not linear._ATTACK_PASS_ONLY
+        d_table = torch.empty_like(table) if want_table else None
+        _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(coef), _ptr(ws), _ptr(d_out), _ptr(d_table),
+                                               _stream()), "full_sort_ce_bwd")
+        return d_out, d_table, None
+
+
+def full_sort_cross_entropy(output: torch.Tensor, table: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """mean_b [ logsumexp_n(output_b . table_n) - output_b . table_target(b) ]"""
+    return _FullSortCE.apply(output.contiguous(), table, target).mean()
+
+
+def supported(hidden_size: int) -> bool:
+    return hidden_size in (64, 128)

@@ -106,4 +106,34 @@ int acattn_rng_materialize(int32_t B, int32_t n_heads, int32_t L, uint64_t seed,
   return rc;
 }
 
+static int check_ce(const acattn_ce_problem* p) {
+  if (!p) return fail("ce problem is NULL");
+  if (p->B < 1 || p->N < 1) return fail("B and N must be positive");
+  if (p->H != 64 && p->H != 128) return fail("unsupported hidden size for the fused cross-entropy: H must be 64 or 128");
+  if (!p->out || !p->table || !p->target) return fail("out, table, target must be non-NULL");
+  return 0;
+}
+
+int64_t acattn_full_sort_ce_workspace_bytes(const acattn_ce_problem* p) {
+  if (!p || (p->H != 64 && p->H != 128)) return -1;
+  return acattn_ce_ws_bytes(*p);
+}
+
+int acattn_full_sort_ce_fwd(const acattn_ce_problem* p, void* workspace, float* lse, float* row_loss, void* stream) {
+  if (int rc = check_ce(p)) return rc;
+  if (!workspace || !lse || !row_loss) return fail("workspace, lse, row_loss must be non-NULL");
+  const int rc = acattn_launch_ce_fwd(*p, workspace, lse, row_loss, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const float* coef, void* workspace,
+                            float* d_out, float* d_table, void* stream) {
+  if (int rc = check_ce(p)) return rc;
+  if (!workspace || !lse || !coef || !d_out) return fail("workspace, lse, coef, d_out must be non-NULL");
+  const int rc = acattn_launch_ce_bwd(*p, lse, coef, workspace, d_out, d_table, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 }  // extern "C"

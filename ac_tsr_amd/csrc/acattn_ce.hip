@@ -1,0 +1,361 @@
+// Full-catalogue cross-entropy without materialising the [B, N] logits, for gfx950 (MI355X).
+//
+// Replaces ACSASRec._cal_loss for loss_type 'CE' (recbole/model/sequential_recommender/acsasrec.py:117-120):
+//     logits = output @ item_embedding.weight^T          [B, N]   (205 MB at 512 x 100k, written and re-read 3x)
+//     loss   = CrossEntropyLoss(logits, pos_items)
+// and its backward.  It is attention with Q = output, K = V = the item table and one "head":
+//     row_loss[b] = logsumexp_n(out_b . E_n) - out_b . E_target(b)
+//     d out_b     = coef_b * (sum_n p_bn E_n - E_target(b)),      d E_n = sum_b coef_b (p_bn - [n == target_b]) out_b
+// Items are stationary: a wave owns 16*TILES table rows for the whole kernel and sweeps the batch in 16-row
+// blocks, computing logits^T = E . out^T with exact-fp32 MFMA (16x16x4).  In that orientation the batch row sits
+// on the lane, so the row statistics are register-local, the logit registers are directly the B operand of
+// d out^T = E^T . dl^T, and d E accumulates in registers over the sweep (no atomics anywhere).  What crosses
+// workgroups is small: (max, sum-exp) pairs per (row, wave) in the forward, one [B, H] slab of d out per
+// workgroup in the backward, each folded by a second tiny kernel.
+#include "acattn_common.h"
+
+namespace {
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+constexpr int CE_NW = 4;  // waves per workgroup
+
+template <int CH>
+struct CeCfg {
+  static constexpr int KS = CH / 4;               // k-steps of a logit tile == fragment floats per lane
+  static constexpr int DT = CH / 16;              // 16-wide column tiles of the hidden dimension
+  static constexpr int TILES = CH <= 64 ? 4 : 2;  // 16-item tiles per wave
+  static constexpr int ITEMS = 16 * TILES;        // table rows owned by one wave
+  static constexpr int ES = CH + 4;               // padded LDS row stride
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: per (row, wave) partial (max, sum exp) of the wave's items
+// ---------------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ void __launch_bounds__(64 * CE_NW) ce_fwd_kernel(const acattn_ce_problem P, float2* __restrict__ part) {
+  using C = CeCfg<CH>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int wid = blockIdx.x * CE_NW + wave;
+  const int item0 = wid * C::ITEMS;
+  const int B = P.B, N = P.N;
+
+  float ef[C::TILES][C::KS];  // A operand: table rows of this wave, lane (c, g) holds row 16t+c, columns KS*g ..
+#pragma unroll
+  for (int t = 0; t < C::TILES; ++t) {
+    const int item = item0 + 16 * t + c;
+#pragma unroll
+    for (int s4 = 0; s4 < C::KS / 4; ++s4) {
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (item < N) v = *(const f4*)(P.table + (size_t)item * CH + C::KS * g + 4 * s4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ef[t][4 * s4 + e] = v[e];
+    }
+  }
+  const int nrb = (B + 15) >> 4;
+  float hf[C::KS];
+  auto load_rows = [&](int rb, float (&dst)[C::KS]) {
+    const int row = 16 * rb + c;
+#pragma unroll
+    for (int s4 = 0; s4 < C::KS / 4; ++s4) {
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < B) v = *(const f4*)(P.out + (size_t)row * CH + C::KS * g + 4 * s4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[4 * s4 + e] = v[e];
+    }
+  };
+  load_rows(0, hf);
+  for (int rb = 0; rb < nrb; ++rb) {
+    float hn[C::KS];
+    if (rb + 1 < nrb) load_rows(rb + 1, hn);  // next block's rows are in flight under this block's MFMAs
+    f4 acc[C::TILES];
+#pragma unroll
+    for (int t = 0; t < C::TILES; ++t) {
+      acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) acc[t] = mfma16(ef[t][s], hf[s], acc[t]);
+    }
+    float m = ACATTN_NEG_INF;
+#pragma unroll
+    for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (item0 + 16 * t + 4 * g + r >= N) acc[t][r] = ACATTN_NEG_INF;
+        m = fmaxf(m, acc[t][r]);
+      }
+    m = quad_max(m);
+    float sum = 0.f;
+    if (m > ACATTN_NEG_INF) {
+#pragma unroll
+      for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum += __builtin_amdgcn_exp2f((acc[t][r] - m) * kLog2e);
+    }
+    sum = quad_sum(sum);
+    const int row = 16 * rb + c;
+    if (g == 0 && row < B) part[(size_t)wid * B + row] = float2{m, sum};
+    if (rb + 1 < nrb) {
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) hf[s] = hn[s];
+    }
+  }
+}
+
+// one wave per batch row: fold the partials, add the target logit
+template <int CH>
+__global__ void __launch_bounds__(256) ce_fwd_reduce_kernel(const acattn_ce_problem P, const float2* __restrict__ part,
+                                                            int n_part, float* __restrict__ lse,
+                                                            float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= P.B) return;
+  float m = ACATTN_NEG_INF, s = 0.f;
+  for (int k = lane; k < n_part; k += 64) {
+    const float2 p = part[(size_t)k * P.B + row];
+    if (p.x > m) {
+      s = s * __builtin_amdgcn_exp2f((m - p.x) * kLog2e) + p.y;
+      m = p.x;
+    } else if (p.x > ACATTN_NEG_INF) {
+      s += p.y * __builtin_amdgcn_exp2f((p.x - m) * kLog2e);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float m2 = __shfl_xor(m, off), s2 = __shfl_xor(s, off);
+    const float mn = fmaxf(m, m2);
+    const float a = m > ACATTN_NEG_INF ? s * __builtin_amdgcn_exp2f((m - mn) * kLog2e) : 0.f;
+    const float b = m2 > ACATTN_NEG_INF ? s2 * __builtin_amdgcn_exp2f((m2 - mn) * kLog2e) : 0.f;
+    m = mn;
+    s = a + b;
+  }
+  const long long tgt = P.target[row];
+  float dot = 0.f;
+  for (int d = lane; d < CH; d += 64) dot += P.out[(size_t)row * CH + d] * P.table[(size_t)tgt * CH + d];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+  if (lane == 0) {
+    const float l = m + __builtin_amdgcn_logf(s) * kLn2;
+    lse[row] = l;
+    row_loss[row] = l - dot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------
+template <int CH, bool WITH_TABLE_GRAD>
+__global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_problem P, const float* __restrict__ lse,
+                                                            const float* __restrict__ coef,
+                                                            float* __restrict__ dout_part,
+                                                            float* __restrict__ d_table) {
+  using C = CeCfg<CH>;
+  constexpr int TS = C::ITEMS + 16;  // transpose-scratch row stride: 16 * odd -> conflict-free column reads
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int item0 = (blockIdx.x * CE_NW + wave) * C::ITEMS;
+  const int B = P.B, N = P.N;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Es = smem + wave * C::ITEMS * C::ES;               // [ITEMS][ES]  this wave's table rows
+  float* Hs = smem + CE_NW * C::ITEMS * C::ES;              // [16][ES]     current batch rows (shared)
+  float* X = Hs + 16 * C::ES;                               // per-wave exchange area, max(16*TS, 16*ES) floats
+  constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
+  float* Xw = X + wave * XS;
+
+  // stage this wave's table rows (zero past the catalogue end)
+  for (int idx = lane; idx < C::ITEMS * (CH / 4); idx += 64) {
+    const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (item0 + r < N) v = *(const f4*)(P.table + (size_t)(item0 + r) * CH + 4 * c4);
+    *(f4*)(Es + r * C::ES + 4 * c4) = v;
+  }
+  f4 dE[C::TILES][C::DT];
+#pragma unroll
+  for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) dE[t][dt] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nrb = (B + 15) >> 4;
+  for (int rb = 0; rb < nrb; ++rb) {
+    __syncthreads();  // Hs and the exchange area of the previous block are free
+    for (int idx = threadIdx.x; idx < 16 * (CH / 4); idx += blockDim.x) {
+      const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (16 * rb + r < B) v = *(const f4*)(P.out + (size_t)(16 * rb + r) * CH + 4 * c4);
+      *(f4*)(Hs + r * C::ES + 4 * c4) = v;
+    }
+    const int row = 16 * rb + c;
+    const bool row_ok = row < B;
+    const float l2 = row_ok ? lse[row] * kLog2e : 0.f;
+    const float cf = row_ok ? coef[row] : 0.f;
+    const int tgt = row_ok ? (int)P.target[row] - item0 : -1;  // target as an index into this wave's items
+    __syncthreads();
+
+    // logits^T tile set and dl = coef * (softmax - onehot), layout: lane = batch row, registers = items
+    float hf[C::KS];
+#pragma unroll
+    for (int s4 = 0; s4 < C::KS / 4; ++s4) {
+      const f4 v = *(const f4*)(Hs + c * C::ES + C::KS * g + 4 * s4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hf[4 * s4 + e] = v[e];
+    }
+    f4 dl[C::TILES];
+#pragma unroll
+    for (int t = 0; t < C::TILES; ++t) {
+      f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < C::KS / 4; ++s4) {
+        const f4 e4 = *(const f4*)(Es + (16 * t + c) * C::ES + C::KS * g + 4 * s4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = mfma16(e4[e], hf[4 * s4 + e], a);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int it = 16 * t + 4 * g + r;
+        float p = (item0 + it < N) ? __builtin_amdgcn_exp2f(a[r] * kLog2e - l2) : 0.f;
+        if (it == tgt) p -= 1.0f;
+        dl[t][r] = p * cf;
+      }
+    }
+    // d out^T (this wave's items) = E^T . dl^T : dl registers are the B operand as they stand
+    f4 dh[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) dh[dt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* ep = Es + (16 * t + 4 * g + r) * C::ES + c;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) dh[dt] = mfma16(ep[16 * dt], dl[t][r], dh[dt]);
+      }
+    if (WITH_TABLE_GRAD) {
+      // d E (this wave's items) += dl^T . out : transpose dl through the wave's exchange area
+#pragma unroll
+      for (int t = 0; t < C::TILES; ++t) *(f4*)(Xw + c * TS + 16 * t + 4 * g) = dl[t];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float bv[4][C::DT];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) bv[s][dt] = Hs[(4 * s + g) * C::ES + 16 * dt + c];
+#pragma unroll
+      for (int t = 0; t < C::TILES; ++t) {
+        float a[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = Xw[(4 * s + g) * TS + 16 * t + c];
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) dE[t][dt] = mfma16(a[s], bv[s][dt], dE[t][dt]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // fold the four waves' d out tiles: each wave parks its [16][CH] tile, then every thread sums one float4
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) *(f4*)(Xw + c * C::ES + 16 * dt + 4 * g) = dh[dt];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 16 * (CH / 4); idx += blockDim.x) {
+      const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+      if (16 * rb + r < B) {
+        f4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < CE_NW; ++w) sum += *(const f4*)(X + w * XS + r * C::ES + 4 * c4);
+        *(f4*)(dout_part + ((size_t)blockIdx.x * B + 16 * rb + r) * CH + 4 * c4) = sum;
+      }
+    }
+  }
+  if (WITH_TABLE_GRAD) {
+#pragma unroll
+    for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int item = item0 + 16 * t + 4 * g + r;
+        if (item < N) {
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) d_table[(size_t)item * CH + 16 * dt + c] = dE[t][dt][r];
+        }
+      }
+  }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256) ce_dout_reduce_kernel(int B, int n_wg, const float* __restrict__ part,
+                                                             float* __restrict__ d_out) {
+  const int total = B * (CH / 4);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    f4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < n_wg; ++k) sum += *(const f4*)(part + ((size_t)k * total + idx) * 4);
+    *(f4*)(d_out + (size_t)idx * 4) = sum;
+  }
+}
+
+template <int CH>
+int64_t ws_bytes(const acattn_ce_problem& p) {
+  using C = CeCfg<CH>;
+  const int64_t n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
+  const int64_t fwd = n_wg * CE_NW * p.B * (int64_t)sizeof(float2);
+  const int64_t bwd = n_wg * p.B * (int64_t)CH * sizeof(float);
+  return fwd > bwd ? fwd : bwd;
+}
+
+template <int CH>
+int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
+  using C = CeCfg<CH>;
+  const int n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
+  hipLaunchKernelGGL((ce_fwd_kernel<CH>), dim3(n_wg), dim3(64 * CE_NW), 0, stream, p, (float2*)ws);
+  hipLaunchKernelGGL((ce_fwd_reduce_kernel<CH>), dim3((p.B + 3) / 4), dim3(256), 0, stream, p, (const float2*)ws,
+                     n_wg * CE_NW, lse, row_loss);
+  return (int)hipGetLastError();
+}
+
+template <int CH>
+int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out, float* d_table,
+               hipStream_t stream) {
+  using C = CeCfg<CH>;
+  const int n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
+  constexpr int TS = C::ITEMS + 16;
+  constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
+  const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
+  if (d_table) {
+    auto k = ce_bwd_kernel<CH, true>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, (float*)ws, d_table);
+  } else {
+    auto k = ce_bwd_kernel<CH, false>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, (float*)ws, d_table);
+  }
+  hipLaunchKernelGGL((ce_dout_reduce_kernel<CH>), dim3(64), dim3(256), 0, stream, p.B, n_wg, (const float*)ws, d_out);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int64_t acattn_ce_ws_bytes(const acattn_ce_problem& p) {
+  switch (p.H) {
+    case 64: return ws_bytes<64>(p);
+    case 128: return ws_bytes<128>(p);
+  }
+  return -1;
+}
+
+int acattn_launch_ce_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
+  switch (p.H) {
+    case 64: return launch_fwd<64>(p, ws, lse, row_loss, stream);
+    case 128: return launch_fwd<128>(p, ws, lse, row_loss, stream);
+  }
+  return -1;
+}
+
+int acattn_launch_ce_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out,
+                         float* d_table, hipStream_t stream) {
+  switch (p.H) {
+    case 64: return launch_bwd<64>(p, lse, coef, ws, d_out, d_table, stream);
+    case 128: return launch_bwd<128>(p, lse, coef, ws, d_out, d_table, stream);
+  }
+  return -1;
+}

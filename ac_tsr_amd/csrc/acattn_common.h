@@ -138,4 +138,8 @@ int acattn_launch_fwd(const acattn_problem& p, const acattn_fwd_out& o, hipStrea
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
 int acattn_launch_rng(int B, int nh, int L, uint64_t seed, float p_drop, float* noise, uint8_t* keep_after,
                       uint8_t* keep_mask, uint8_t* keep_before, hipStream_t stream);
+int64_t acattn_ce_ws_bytes(const acattn_ce_problem& p);
+int acattn_launch_ce_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream);
+int acattn_launch_ce_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out,
+                         float* d_table, hipStream_t stream);
 void acattn_set_error(const char* msg);

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from .layers import AttackRTransformerEncoder
+from . import ce
 from .linear import embedding_lookup, full_sort_scores
 from .ops import StructuredMask
 
@@ -154,6 +155,9 @@ class ACSASRec(SequentialRecommender):
             pos_score = torch.sum(output * self.item_embedding(pos_items), dim=-1)
             neg_score = torch.sum(output * self.item_embedding(neg_items), dim=-1)
             return self.loss_fct(pos_score, neg_score)
+        if output.is_cuda and ce.supported(self.hidden_size) and torch.is_grad_enabled():
+            # fused: the [B, n_items] logits (205 MB at 512 x 100k) are never written
+            return ce.full_sort_cross_entropy(output, self.item_embedding.weight, pos_items)
         logits = full_sort_scores(output, self.item_embedding.weight)
         return self.loss_fct(logits, pos_items)
 

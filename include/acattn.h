@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 2
+#define ACATTN_ABI_VERSION 3
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -122,6 +122,26 @@ typedef struct acattn_bwd_io {
   float* dw_dist_part;  /* [B,nh,2*dh] */
   float* dsmall_part;   /* [B,nh,4]: d b_order, d b_dist, d scalar, d rich_ratio */
 } acattn_bwd_io;
+
+/* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
+ * recbole/model/sequential_recommender/acsasrec.py:117-120, without materialising the [B, N] logits. */
+typedef struct acattn_ce_problem {
+  int32_t B, N, H;       /* rows (sequences), catalogue size, hidden size (64 or 128) */
+  const float* out;      /* [B,H] sequence representations (attacked_output / calibrated_output)  acsasrec.py:101-103 */
+  const float* table;    /* [N,H] item_embedding.weight                                           acsasrec.py:117 */
+  const int64_t* target; /* [B]   pos_items                                                      acsasrec.py:108 */
+} acattn_ce_problem;
+
+/* Bytes of scratch both CE entry points need (caller-allocated device memory, contents irrelevant). */
+int64_t acattn_full_sort_ce_workspace_bytes(const acattn_ce_problem* p);
+
+/* lse[b] = logsumexp_n(out_b . table_n);  row_loss[b] = lse[b] - out_b . table_target(b).
+ * mean(row_loss) == CrossEntropyLoss(out @ table^T, target)   (acsasrec.py:118-120). */
+int acattn_full_sort_ce_fwd(const acattn_ce_problem* p, void* workspace, float* lse, float* row_loss, void* stream);
+
+/* Gradients of sum_b coef[b] * row_loss[b]: d_out [B,H] always; d_table [N,H] (fully overwritten) unless NULL. */
+int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const float* coef, void* workspace,
+                            float* d_out, float* d_table, void* stream);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);
