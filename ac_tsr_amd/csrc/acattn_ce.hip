@@ -20,21 +20,23 @@ constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 constexpr int CE_NW = 4;  // waves per workgroup
 
-template <int CH>
+// NTILES (16-item tiles per wave) is picked per launch so that one round of workgroups covers the catalogue
+// (e.g. 100k items: 7 tiles -> 224 workgroups of 448 items on 256 CUs) instead of a ragged second round.
+template <int CH, int NTILES>
 struct CeCfg {
-  static constexpr int KS = CH / 4;               // k-steps of a logit tile == fragment floats per lane
-  static constexpr int DT = CH / 16;              // 16-wide column tiles of the hidden dimension
-  static constexpr int TILES = CH <= 64 ? 4 : 2;  // 16-item tiles per wave
-  static constexpr int ITEMS = 16 * TILES;        // table rows owned by one wave
-  static constexpr int ES = CH + 4;               // padded LDS row stride
+  static constexpr int KS = CH / 4;         // k-steps of a logit tile == fragment floats per lane
+  static constexpr int DT = CH / 16;        // 16-wide column tiles of the hidden dimension
+  static constexpr int TILES = NTILES;      // 16-item tiles per wave
+  static constexpr int ITEMS = 16 * TILES;  // table rows owned by one wave
+  static constexpr int ES = CH + 4;         // padded LDS row stride
 };
 
 // ---------------------------------------------------------------------------------------------------------
 // forward: per (row, wave) partial (max, sum exp) of the wave's items
 // ---------------------------------------------------------------------------------------------------------
-template <int CH>
+template <int CH, int NTILES>
 __global__ void __launch_bounds__(64 * CE_NW) ce_fwd_kernel(const acattn_ce_problem P, float2* __restrict__ part) {
-  using C = CeCfg<CH>;
+  using C = CeCfg<CH, NTILES>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
@@ -145,13 +147,13 @@ __global__ void __launch_bounds__(256) ce_fwd_reduce_kernel(const acattn_ce_prob
 // ---------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------
-template <int CH, bool WITH_TABLE_GRAD>
+template <int CH, int NTILES, bool WITH_TABLE_GRAD>
 __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_problem P, const float* __restrict__ lse,
                                                             const float* __restrict__ coef,
-                                                            float* __restrict__ dout_part,
+                                                            float* __restrict__ d_out,
                                                             float* __restrict__ d_table) {
-  using C = CeCfg<CH>;
-  constexpr int TS = C::ITEMS + 16;  // transpose-scratch row stride: 16 * odd -> conflict-free column reads
+  using C = CeCfg<CH, NTILES>;
+  constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);  // transpose-scratch row stride: 16 * odd -> conflict-free column reads
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
@@ -264,7 +266,11 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         f4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < CE_NW; ++w) sum += *(const f4*)(X + w * XS + r * C::ES + 4 * c4);
-        *(f4*)(dout_part + ((size_t)blockIdx.x * B + 16 * rb + r) * CH + 4 * c4) = sum;
+        // one [16, CH] tile per workgroup and row block: ~50 MB of float atomics per call, spread over all rows and
+        // issued under the MFMA work of the next block (d_out is zeroed by the launcher)
+        float* dst = d_out + (size_t)(16 * rb + r) * CH + 4 * c4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, sum[e]);
       }
     }
   }
@@ -282,55 +288,93 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
   }
 }
 
-template <int CH>
-__global__ void __launch_bounds__(256) ce_dout_reduce_kernel(int B, int n_wg, const float* __restrict__ part,
-                                                             float* __restrict__ d_out) {
-  const int total = B * (CH / 4);
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    f4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < n_wg; ++k) sum += *(const f4*)(part + ((size_t)k * total + idx) * 4);
-    *(f4*)(d_out + (size_t)idx * 4) = sum;
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
   }
+  return n;
 }
 
 template <int CH>
-int64_t ws_bytes(const acattn_ce_problem& p) {
-  using C = CeCfg<CH>;
-  const int64_t n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
-  const int64_t fwd = n_wg * CE_NW * p.B * (int64_t)sizeof(float2);
-  const int64_t bwd = n_wg * p.B * (int64_t)CH * sizeof(float);
-  return fwd > bwd ? fwd : bwd;
+constexpr int max_tiles() { return CH <= 64 ? 7 : 3; }
+
+// smallest tile count whose single round of (#CUs) workgroups covers N items
+template <int CH>
+int pick_tiles(int N) {
+  const int per_tile = num_cus() * CE_NW * 16;
+  const int need = (N + per_tile - 1) / per_tile;
+  if (CH <= 64) return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
+  return need <= 1 ? 1 : need <= 2 ? 2 : 3;
 }
 
-template <int CH>
-int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
-  using C = CeCfg<CH>;
+template <int CH, int NTILES>
+int launch_fwd_t(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
+  using C = CeCfg<CH, NTILES>;
   const int n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
-  hipLaunchKernelGGL((ce_fwd_kernel<CH>), dim3(n_wg), dim3(64 * CE_NW), 0, stream, p, (float2*)ws);
+  hipLaunchKernelGGL((ce_fwd_kernel<CH, NTILES>), dim3(n_wg), dim3(64 * CE_NW), 0, stream, p, (float2*)ws);
   hipLaunchKernelGGL((ce_fwd_reduce_kernel<CH>), dim3((p.B + 3) / 4), dim3(256), 0, stream, p, (const float2*)ws,
                      n_wg * CE_NW, lse, row_loss);
   return (int)hipGetLastError();
 }
 
+template <int CH, int NTILES>
+int launch_bwd_t(const acattn_ce_problem& p, const float* lse, const float* coef, float* d_out, float* d_table,
+                 hipStream_t stream) {
+  using C = CeCfg<CH, NTILES>;
+  const int n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
+  constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);
+  constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
+  const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
+  const hipError_t e = hipMemsetAsync(d_out, 0, (size_t)p.B * CH * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  if (d_table) {
+    auto k = ce_bwd_kernel<CH, NTILES, true>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, d_table);
+  } else {
+    auto k = ce_bwd_kernel<CH, NTILES, false>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, d_table);
+  }
+  return (int)hipGetLastError();
+}
+
+template <int CH>
+int64_t ws_bytes(const acattn_ce_problem& p) {
+  // forward partials: one (max, sum-exp) pair per (wave, row)
+  int tiles = pick_tiles<CH>(p.N);
+  if (CH <= 64 && tiles == 3) tiles = 4;
+  if (tiles > max_tiles<CH>()) tiles = max_tiles<CH>();
+  const int64_t n_wg = (p.N + CE_NW * 16 * tiles - 1) / (CE_NW * 16 * tiles);
+  return n_wg * CE_NW * p.B * (int64_t)sizeof(float2);
+}
+
+template <int CH>
+int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
+  switch (pick_tiles<CH>(p.N)) {
+    case 1: return launch_fwd_t<CH, 1>(p, ws, lse, row_loss, stream);
+    case 2: return launch_fwd_t<CH, 2>(p, ws, lse, row_loss, stream);
+    case 3: return launch_fwd_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, stream);
+    case 4: return launch_fwd_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, stream);
+    default: return launch_fwd_t<CH, max_tiles<CH>()>(p, ws, lse, row_loss, stream);
+  }
+}
+
 template <int CH>
 int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out, float* d_table,
                hipStream_t stream) {
-  using C = CeCfg<CH>;
-  const int n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
-  constexpr int TS = C::ITEMS + 16;
-  constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
-  const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
-  if (d_table) {
-    auto k = ce_bwd_kernel<CH, true>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, (float*)ws, d_table);
-  } else {
-    auto k = ce_bwd_kernel<CH, false>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, (float*)ws, d_table);
+  (void)ws;
+  switch (pick_tiles<CH>(p.N)) {
+    case 1: return launch_bwd_t<CH, 1>(p, lse, coef, d_out, d_table, stream);
+    case 2: return launch_bwd_t<CH, 2>(p, lse, coef, d_out, d_table, stream);
+    case 3: return launch_bwd_t<CH, (CH <= 64 ? 4 : 3)>(p, lse, coef, d_out, d_table, stream);
+    case 4: return launch_bwd_t<CH, (CH <= 64 ? 4 : 3)>(p, lse, coef, d_out, d_table, stream);
+    default: return launch_bwd_t<CH, max_tiles<CH>()>(p, lse, coef, d_out, d_table, stream);
   }
-  hipLaunchKernelGGL((ce_dout_reduce_kernel<CH>), dim3(64), dim3(256), 0, stream, p.B, n_wg, (const float*)ws, d_out);
-  return (int)hipGetLastError();
 }
 
 }  // namespace
