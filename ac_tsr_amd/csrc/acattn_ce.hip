@@ -74,11 +74,13 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_fwd_kernel(const acattn_ce_prob
     if (rb + 1 < nrb) load_rows(rb + 1, hn);  // next block's rows are in flight under this block's MFMAs
     f4 acc[C::TILES];
 #pragma unroll
-    for (int t = 0; t < C::TILES; ++t) {
-      acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < C::TILES; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    // k-step outer, tiles inner: consecutive MFMAs hit different accumulators (a dependent 16x16x4 chain
+    // issues every 40 cycles, independent ones every 32)
 #pragma unroll
-      for (int s = 0; s < C::KS; ++s) acc[t] = mfma16(ef[t][s], hf[s], acc[t]);
-    }
+    for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+      for (int t = 0; t < C::TILES; ++t) acc[t] = mfma16(ef[t][s], hf[s], acc[t]);
     float m = ACATTN_NEG_INF;
 #pragma unroll
     for (int t = 0; t < C::TILES; ++t)
@@ -207,13 +209,16 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
     f4 dl[C::TILES];
 #pragma unroll
     for (int t = 0; t < C::TILES; ++t) {
-      f4 a = {0.f, 0.f, 0.f, 0.f};
+      f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;  // two interleaved chains (see the forward)
 #pragma unroll
       for (int s4 = 0; s4 < C::KS / 4; ++s4) {
         const f4 e4 = *(const f4*)(Es + (16 * t + c) * C::ES + C::KS * g + 4 * s4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a = mfma16(e4[e], hf[4 * s4 + e], a);
+        a0 = mfma16(e4[0], hf[4 * s4 + 0], a0);
+        a1 = mfma16(e4[1], hf[4 * s4 + 1], a1);
+        a0 = mfma16(e4[2], hf[4 * s4 + 2], a0);
+        a1 = mfma16(e4[3], hf[4 * s4 + 3], a1);
       }
+      const f4 a = a0 + a1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int it = 16 * t + 4 * g + r;
@@ -250,9 +255,9 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
 #pragma unroll
         for (int s = 0; s < 4; ++s) a[s] = Xw[(4 * s + g) * TS + 16 * t + c];
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) dE[t][dt] = mfma16(a[s], bv[s][dt], dE[t][dt]);
+          for (int dt = 0; dt < C::DT; ++dt) dE[t][dt] = mfma16(a[s], bv[s][dt], dE[t][dt]);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
