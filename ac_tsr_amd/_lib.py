@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libacattn.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -58,6 +58,14 @@ class CeProblem(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("out", _f), ("table", _f), ("target", _f)]
 
 
+class LnProblem(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("H", C.c_int32), ("residual_rows", C.c_int32), ("z", _f), ("residual", _f),
+                ("gamma", _f), ("beta", _f), ("eps", C.c_float), ("p_drop", C.c_float), ("keep", _f),
+                ("seed", C.c_uint64), ("seed_device", _f)]
+
+
+LN_BWD_GRID = 512
+
 # name -> (restype, argtypes); must list every symbol include/acattn.h declares (tests check this)
 SYMBOLS = {
     "acattn_abi_version": (C.c_int, []),
@@ -68,6 +76,8 @@ SYMBOLS = {
     "acattn_full_sort_ce_workspace_bytes": (C.c_int64, [C.POINTER(CeProblem)]),
     "acattn_full_sort_ce_fwd": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, C.c_void_p]),
     "acattn_full_sort_ce_bwd": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, _f, _f, C.c_void_p]),
+    "acattn_dropout_add_layernorm_fwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, C.c_void_p]),
+    "acattn_dropout_add_layernorm_bwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, _f, _f, _f, C.c_void_p]),
     "acattn_rng_materialize": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, _f, _f, _f, _f,
                                          C.c_void_p]),
 }

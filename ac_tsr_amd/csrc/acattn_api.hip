@@ -136,4 +136,31 @@ int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const 
   return rc;
 }
 
+static int check_ln(const acattn_ln_problem* p) {
+  if (!p) return fail("ln problem is NULL");
+  if (p->rows < 1) return fail("rows must be positive");
+  if (p->H != 64 && p->H != 128 && p->H != 256) return fail("unsupported hidden size for the fused LayerNorm: H must be 64, 128 or 256");
+  if (p->residual_rows < 1 || p->rows % p->residual_rows != 0) return fail("residual_rows must divide rows");
+  if (!p->z || !p->residual || !p->gamma || !p->beta) return fail("z, residual, gamma, beta must be non-NULL");
+  if (p->p_drop < 0.f || p->p_drop >= 1.f) return fail("p_drop must lie in [0, 1)");
+  return 0;
+}
+
+int acattn_dropout_add_layernorm_fwd(const acattn_ln_problem* p, float* y, float* stats, void* stream) {
+  if (int rc = check_ln(p)) return rc;
+  if (!y || !stats) return fail("y and stats must be non-NULL");
+  const int rc = acattn_launch_ln_fwd(*p, y, stats, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy, const float* stats, float* dz,
+                                     float* dres, float* dgb_part, void* stream) {
+  if (int rc = check_ln(p)) return rc;
+  if (!dy || !stats) return fail("dy and stats must be non-NULL");
+  const int rc = acattn_launch_ln_bwd(*p, dy, stats, dz, dres, dgb_part, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 }  // extern "C"

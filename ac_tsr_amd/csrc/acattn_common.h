@@ -142,4 +142,7 @@ int64_t acattn_ce_ws_bytes(const acattn_ce_problem& p);
 int acattn_launch_ce_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream);
 int acattn_launch_ce_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out,
                          float* d_table, hipStream_t stream);
+int acattn_launch_ln_fwd(const acattn_ln_problem& p, float* y, float* stats, hipStream_t stream);
+int acattn_launch_ln_bwd(const acattn_ln_problem& p, const float* dy, const float* stats, float* dz, float* dres,
+                         float* dgb_part, hipStream_t stream);
 void acattn_set_error(const char* msg);

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import fused_ln, ops
 from .linear import skinny_linear
 from .ops import AttentionConfig, ExplicitRandomness, StructuredMask
 
@@ -83,6 +83,9 @@ class AttackRMultiHeadAttention(nn.Module):
     def output(self, context_layer, input_tensor, _keep=None):
         """dense -> dropout -> LayerNorm(+residual) of cal_adjusted_outputs (layers.py:681-683)."""
         hidden_states = skinny_linear(context_layer, self.dense)
+        if hidden_states.is_cuda and fused_ln.supported(hidden_states.shape[-1]):
+            return fused_ln.dropout_add_layer_norm(hidden_states, input_tensor, self.LayerNorm, self.out_dropout.p,
+                                                   self.training, _keep)
         if _keep is not None:
             hidden_states = hidden_states * (_keep.to(hidden_states.dtype) / (1.0 - self.out_dropout.p))
         else:
@@ -119,6 +122,9 @@ class FeedForward(nn.Module):
 
     def forward(self, input_tensor, _keep=None):
         hidden_states = skinny_linear(self.intermediate_act_fn(skinny_linear(input_tensor, self.dense_1)), self.dense_2)
+        if hidden_states.is_cuda and fused_ln.supported(hidden_states.shape[-1]):
+            return fused_ln.dropout_add_layer_norm(hidden_states, input_tensor, self.LayerNorm, self.dropout.p,
+                                                   self.training, _keep)
         if _keep is not None:
             hidden_states = hidden_states * (_keep.to(hidden_states.dtype) / (1.0 - self.dropout.p))
         else:

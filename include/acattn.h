@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 3
+#define ACATTN_ABI_VERSION 4
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -142,6 +142,31 @@ int acattn_full_sort_ce_fwd(const acattn_ce_problem* p, void* workspace, float* 
 /* Gradients of sum_b coef[b] * row_loss[b]: d_out [B,H] always; d_table [N,H] (fully overwritten) unless NULL. */
 int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const float* coef, void* workspace,
                             float* d_out, float* d_table, void* stream);
+
+/* y = LayerNorm(dropout(z) + residual) * gamma + beta   (the tail of both sub-blocks
+ * of a layer -- recbole/model/layers.py:681-683 and :794-796).  Rows of H in {64, 128, 256} floats. */
+#define ACATTN_LN_BWD_GRID 512 /* workgroups of the backward == rows of its dgamma/dbeta partial buffer */
+typedef struct acattn_ln_problem {
+  int32_t rows, H;
+  int32_t residual_rows;  /* == rows, or a divisor of it when the residual is broadcast over a leading dimension */
+  const float* z;         /* [rows,H] output of the dense layer (bias included) */
+  const float* residual;  /* [residual_rows,H] */
+  const float* gamma;     /* [H] LayerNorm.weight */
+  const float* beta;      /* [H] LayerNorm.bias */
+  float eps;              /* layer_norm_eps */
+  float p_drop;           /* hidden_dropout_prob in training, 0 in eval */
+  const uint8_t* keep;    /* optional explicit keep mask [rows,H]; NULL = counter RNG from (seed, seed_device) */
+  uint64_t seed;
+  const uint64_t* seed_device;
+} acattn_ln_problem;
+
+/* stats[rows,2] receives (mean, 1/std) per row for the backward. */
+int acattn_dropout_add_layernorm_fwd(const acattn_ln_problem* p, float* y, float* stats, void* stream);
+
+/* dz [rows,H] and dres [rows,H] may each be NULL; dgb_part is [ACATTN_LN_BWD_GRID, 2, H] partial sums of
+ * (dgamma, dbeta), or NULL; the caller adds the partials (and folds dres when the residual was broadcast). */
+int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy, const float* stats, float* dz,
+                                     float* dres, float* dgb_part, void* stream);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);
