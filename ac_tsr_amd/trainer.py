@@ -69,7 +69,9 @@ class AttackSASRecTrainer:
         if self.grad_sync is not None:
             self.grad_sync.zero_grad()
         else:
-            self.optimizer.zero_grad(set_to_none=False)
+            # None instead of zeros: the first gradient that reaches a leaf is then stored, not added to a zero
+            # buffer (one fill + one add kernel less per parameter and step)
+            self.optimizer.zero_grad(set_to_none=True)
         attacked_loss, calibrated_loss = self.model.calculate_loss(interaction)
         if check_nan:
             if attacked_loss is not None:
