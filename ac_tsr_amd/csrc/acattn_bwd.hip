@@ -786,7 +786,11 @@ int launch_dh(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stre
 
 }  // namespace
 
+int acattn_launch_bwd_fast(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
+
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
+  const int rc_fast = acattn_launch_bwd_fast(p, io, stream);  // training hot path (L <= 64); -100 = not applicable
+  if (rc_fast != -100) return rc_fast;
   if (!p.two_level) {
     acattn_set_error("backward supports two_level = 1 only (every shipped reference config)");
     return -1;

@@ -205,3 +205,43 @@ def test_graph_mode_matches_eager_and_redraws_randomness():
         att, cal = trainer.train_step(batch)
     assert cal.item() < first - 0.3, (first, cal.item())
     A.ops.set_graph_seed_tensor(None)
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("p_drop", [0.0, 0.5])
+@pytest.mark.parametrize("shape", [(64, 50, 64, 2), (12, 50, 64, 4), (8, 64, 128, 2), (6, 37, 64, 2)])
+def test_fast_training_backward_equals_general_backward(causal, p_drop, shape):
+    """acattn_bwd_fast.hip (counter RNG, gate, structured mask) against the general backward fed the same draws as
+    explicit tensors (itself pinned to the oracle's autograd above): every gradient of the fused operator."""
+    B, L, H, nh = shape
+    g = torch.Generator().manual_seed(21)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    base = {k: mk(B, L, H) for k in ("q", "k", "v", "qa", "ka")}
+    base["gl"] = mk(B, L, L)
+    dh = H // nh
+    for k, shp in (("w_order", (1, 2 * dh)), ("b_order", (1,)), ("w_dist", (1, 2 * dh)), ("b_dist", (1,)), ("scalar", (1,))):
+        base[k] = (0.3 * torch.randn(*shp, generator=g)).to(DEV)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    kv = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(DEV)
+    mask = A.StructuredMask(kv, causal=causal)
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
+    cot = [mk(B, L, H), mk(B, L, H), mk(B, nh, L, L)]
+    seed = 4242
+
+    def grads(rnd):
+        t = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        out = A.calibrated_attention(t["q"], t["k"], t["v"], t["qa"], t["ka"], t["gl"], mask, cfg, p_drop=p_drop,
+                                     seed=None if rnd is not None else seed, rnd=rnd, w_order=t["w_order"],
+                                     b_order=t["b_order"], w_dist=t["w_dist"], b_dist=t["b_dist"], scalar=t["scalar"])
+        loss = sum((o * c_).sum() for o, c_ in zip(out[:3], cot))
+        names = list(t)
+        return dict(zip(names, torch.autograd.grad(loss, [t[n] for n in names])))
+
+    fast = grads(None)
+    rnd = A.materialize_randomness(B, nh, L, seed, p_drop, DEV)
+    if p_drop == 0.0:
+        rnd = A.ExplicitRandomness(noise=rnd.noise)
+    ref = grads(rnd)
+    for n in ref:
+        scale = ref[n].abs().max().item()
+        assert (fast[n] - ref[n]).abs().max().item() <= 2e-4 * scale + 1e-7, (n, (fast[n] - ref[n]).abs().max().item(), scale)
