@@ -163,4 +163,12 @@ int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy
   return rc;
 }
 
+int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_t C, void* stream) {
+  if (!x || !out) return fail("x and out must be non-NULL");
+  if (batch < 1 || R < 1 || C < 1) return fail("batch, R, C must be positive");
+  const int rc = acattn_launch_sum_rows(x, out, batch, R, C, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 }  // extern "C"

@@ -145,4 +145,5 @@ int acattn_launch_ce_bwd(const acattn_ce_problem& p, const float* lse, const flo
 int acattn_launch_ln_fwd(const acattn_ln_problem& p, float* y, float* stats, hipStream_t stream);
 int acattn_launch_ln_bwd(const acattn_ln_problem& p, const float* dy, const float* stats, float* dz, float* dres,
                          float* dgb_part, hipStream_t stream);
+int acattn_launch_sum_rows(const float* x, float* out, int batch, int R, int C, hipStream_t stream);
 void acattn_set_error(const char* msg);

@@ -61,10 +61,10 @@ class _DropoutAddLayerNorm(torch.autograd.Function):
                                                         _ptr(part), _stream()), "dropout_add_layernorm_bwd")
         dres = dres_full
         if dres_full is not None and not same:
-            dres = dres_full.view(-1, *res.shape).sum(0)
+            dres = ops.sum_rows(dres_full.view(-1, *res.shape), 0)
         dgamma = dbeta = None
         if part is not None:
-            gb = part.sum(0)
+            gb = ops.sum_rows(part, 0)
             dgamma, dbeta = gb[0], gb[1]
         return dz, dres, dgamma, dbeta, None, None, None, None, None
 

@@ -15,6 +15,11 @@ import torch
 import torch.nn.functional as F
 
 
+def _sum_rows(x, dim):
+    from .ops import sum_rows  # late import: ops imports nothing from here, but keeps module load order simple
+    return sum_rows(x, dim)
+
+
 # Set by the trainer while the attacked loss is being differentiated (second backward pass): only the attack
 # transforms accumulate there (recbole/trainer/trainer.py:678-684), so every other layer's weight / bias
 # gradient would be computed and thrown away.  A Python autograd.Function cannot see which of its outputs the
@@ -66,11 +71,11 @@ class _SkinnyLinear(torch.autograd.Function):
             m = x2.shape[0]
             s = _split(m)
             if s > 1:
-                gw = torch.bmm(g2.view(s, m // s, -1).transpose(1, 2), x2.view(s, m // s, -1)).sum(0)
+                gw = _sum_rows(torch.bmm(g2.view(s, m // s, -1).transpose(1, 2), x2.view(s, m // s, -1)), 0)
             else:
                 gw = g2.t() @ x2
         if ctx.has_bias and ctx.needs_input_grad[2] and want_params:
-            gb = g2.sum(0)
+            gb = _sum_rows(g2, 0)
         return gx, gw, gb, None
 
 
@@ -101,7 +106,7 @@ class _FullSortScores(torch.autograd.Function):
             s = _split(n)
             if s > 1:
                 b = g.shape[0]
-                g_out = torch.bmm(g.view(b, s, n // s).transpose(0, 1), table.view(s, n // s, -1)).sum(0)
+                g_out = _sum_rows(torch.bmm(g.view(b, s, n // s).transpose(0, 1), table.view(s, n // s, -1)), 0)
             else:
                 g_out = g @ table
         if ctx.needs_input_grad[1] and not _ATTACK_PASS_ONLY:

@@ -246,11 +246,11 @@ class _CalibratedAttention(torch.autograd.Function):
         io.dw_order_part, io.dw_dist_part, io.dsmall_part = _ptr(dwo), _ptr(dwd), _ptr(dsm)
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
         if dgate_part is not None:
-            dgate = dgate_part.sum(dim=1)  # the gate is shared by the heads (layers.py:887 unsqueeze(1))
-        small = dsm.sum(dim=(0, 1))
-        g_wo = dwo.sum(dim=(0, 1)).view_as(w_order) if w_order is not None else None
+            dgate = sum_rows(dgate_part, 1)  # the gate is shared by the heads (layers.py:887 unsqueeze(1))
+        small = sum_rows(dsm.view(-1, 4), 0)
+        g_wo = sum_rows(dwo.view(-1, 2 * dh), 0).view_as(w_order) if w_order is not None else None
         g_bo = small[0:1].view_as(b_order) if w_order is not None else None
-        g_wd = dwd.sum(dim=(0, 1)).view_as(w_dist) if w_dist is not None else None
+        g_wd = sum_rows(dwd.view(-1, 2 * dh), 0).view_as(w_dist) if w_dist is not None else None
         g_bd = small[1:2].view_as(b_dist) if w_dist is not None else None
         g_sc = small[2:3].view_as(scalar) if w_dist is not None else None
         g_rr = small[3:4].view_as(rich_ratio) if rich_ratio is not None else None
@@ -293,3 +293,36 @@ def fwd_algorithmic_bytes(B, L, H, n_heads, adversarial=True, combine_option="ga
     prob.B, prob.L, prob.H, prob.n_heads = B, L, H, n_heads
     prob.adversarial, prob.combine_option = int(adversarial), _lib.COMBINE[combine_option]
     return int(_lib.load().acattn_fwd_algorithmic_bytes(C.byref(prob)))
+
+
+def _launch_sum_rows(x, batch, R, Cn, out_shape):
+    out = torch.empty(out_shape, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().acattn_sum_rows(_ptr(x), _ptr(out), batch, R, Cn, _stream()), "sum_rows")
+    return out
+
+
+def sum_rows(x: torch.Tensor, dim: int = 0) -> torch.Tensor:
+    """x.sum(dim) for a contiguous fp32 HIP tensor through acattn_sum_rows (dims before `dim` form the batch, dims
+    after it the columns).  A long reduction with few output columns (a bias gradient: 25,600 rows x 64) is done in
+    two stages, first into `s` partial rows per batch, so that the first stage fills the chip.  No autograd: used
+    inside backward functions."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.numel() == 0:
+        return x.sum(dim)
+    x = x.contiguous()
+    dim = dim % x.dim()
+    batch = 1
+    for s_ in x.shape[:dim]:
+        batch *= s_
+    R = x.shape[dim]
+    out_shape = tuple(x.shape[:dim]) + tuple(x.shape[dim + 1:])
+    Cn = x.numel() // (batch * R)
+    wgs = batch * ((Cn + 1023) // 1024)
+    if wgs < 128 and R >= 1024:
+        s = 1
+        for cand in range(2, 257):
+            if R % cand == 0 and R // cand >= 16:
+                s = cand
+        if s > 1:
+            part = _launch_sum_rows(x, batch * s, R // s, Cn, (batch, s, Cn))
+            return _launch_sum_rows(part, batch, s, Cn, out_shape)
+    return _launch_sum_rows(x, batch, R, Cn, out_shape)

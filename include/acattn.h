@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 4
+#define ACATTN_ABI_VERSION 5
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -167,6 +167,10 @@ int acattn_dropout_add_layernorm_fwd(const acattn_ln_problem* p, float* y, float
  * (dgamma, dbeta), or NULL; the caller adds the partials (and folds dres when the residual was broadcast). */
 int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy, const float* stats, float* dz,
                                      float* dres, float* dgb_part, void* stream);
+
+/* out[bt, c] = sum_r x[bt, r, c]  (x is [batch, R, C] contiguous).  The reductions of the training step's backward:
+ * bias gradients (sum over B*L rows), split-K slabs, per-(b,head) parameter partials, per-head gate gradients. */
+int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_t C, void* stream);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);

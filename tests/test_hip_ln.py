@@ -56,3 +56,15 @@ def test_fused_ln_counter_dropout_statistics_and_replay():
     assert torch.isfinite(dz).all()
     assert (dz[y1 <= 0] == 0).all()  # nothing flows back through dropped entries ...
     assert (dz[y1 > 0] != 0).float().mean() > 0.999  # ... and (generically) something through every kept one
+
+
+@pytest.mark.parametrize("shape,dim", [((25600, 64), 0), ((128, 64, 64), 0), ((512, 2, 2500), 1), ((1024, 4), 0),
+                                       ((7, 3, 5), 1), ((512, 128), 0), ((33, 50), 0)])
+def test_sum_rows_kernel(shape, dim):
+    from ac_tsr_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(DEV)
+    got = ops.sum_rows(x, dim)
+    want = x.double().sum(dim)
+    assert got.shape == want.shape
+    assert (got.double() - want).abs().max() <= 1e-4 * max(1.0, want.abs().max().item())
