@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=300)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--force-grad-sync", action="store_true",
+                    help="use the data-parallel gradient path (flat buffer, graph without optimizer) even on one GPU")
     return ap.parse_args()
 
 
@@ -214,7 +216,7 @@ def main():
     torch.manual_seed(42)  # config/*.yaml seed: 42 -- identical initial parameters on every rank
     model = A.ACSASRec(A.DictConfig(model_config(a)), A.ItemCount(a.items)).to(device)
     parallel.broadcast_parameters(model)
-    sync = parallel.GradSynchronizer(model.parameters()) if world > 1 else None
+    sync = parallel.GradSynchronizer(model.parameters()) if (world > 1 or a.force_grad_sync) else None
     trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model, grad_sync=sync)
     model.train()
     gen = torch.Generator().manual_seed(1000 + rank)
