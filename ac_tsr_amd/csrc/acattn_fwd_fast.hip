@@ -238,220 +238,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
     return km4;
   };
 
-  auto body = [&](auto ntb_c) {
-    constexpr int NTB = decltype(ntb_c)::value;
-
-    // ---- pass 1: S^T = K.Q^T, Sa^T = Ka.Qa^T; spatial calibrator; first-level softmaxes ----------------
-    f4 tS[NTB], tM[NTB];
-#pragma unroll
-    for (int t = 0; t < NTB; ++t) {
-      __builtin_amdgcn_sched_barrier(0);
-      const float* kp = Ks + (16 * t + c) * VS + KS * g;
-      const float* kap = Kas + (16 * t + c) * VS + KS * g;
-      f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS;
-#pragma unroll
-      for (int s4 = 0; s4 < KS / 4; ++s4) {
-        const f4 k4 = *(const f4*)(kp + 4 * s4);
-        f4 ka4;
-        if (ADV) ka4 = *(const f4*)(kap + 4 * s4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          aS = mfma16(k4[e], qf[4 * s4 + e], aS);
-          if (ADV) aM = mfma16(ka4[e], qaf[4 * s4 + e], aM);
-        }
-      }
-      tS[t] = aS;
-      tM[t] = aM;
-    }
-    // All plain arithmetic below is written on 4-wide vectors (the lane's 4 consecutive keys of a tile) so
-    // that it lowers to packed fp32 instructions (v_pk_fma/mul/add_f32: two elements per issue slot);
-    // only the transcendentals and selects are per component.
-    float mx = ACATTN_NEG_INF, my = ACATTN_NEG_INF, shl = ACATTN_NEG_INF;
-#pragma unroll
-    for (int t = 0; t < NTB; ++t) {
-      const f4 co4 = *(const f4*)(s_co + 16 * t + 4 * g);  // -log2e * (k_j . w_order[dh:])
-      const f4 cd4 = *(const f4*)(s_cd + 16 * t + 4 * g);
-      const f4 mk4 = mask4(t);
-      const bool diag = 16 * t + 15 > i0;  // wave-uniform: the tile holds keys at or after some query of the block
-      const f4 ea = co4 + ao2;
-      f4 val, lt4;
-      const int d0 = i - (16 * t + 4 * g);  // distance of key r is |d0 - r|
-      if (diag) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr = fast_rcp(1.0f + ex2(ea[r]));
-          val[r] = (d0 - r < 0) ? pr : 1.0f - pr;  // layers.py:715-719: key after the query -> log(p), else log(1 - p)
-          const int dist = d0 - r < 0 ? r - d0 : d0 - r;
-          lt4[r] = s_lt[dist];
-        }
-      } else {
-        const float* lp = s_lt + d0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          val[r] = 1.0f - fast_rcp(1.0f + ex2(ea[r]));
-          lt4[r] = lp[-r];
-        }
-      }
-      f4 lg;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lg[r] = __builtin_amdgcn_logf(val[r] + ACATTN_LOG_EPS);
-      const f4 df = lt4 - (cd4 + ad);                        // layers.py:721-726
-      f4 x = tS[t] * scale2 + mk4;                           // (S + e_o + e_d) / sqrt(dh) + mask, exp2 domain
-      x = lg * inv_sqrt + x;                                 // log2(.) * ln2 * scale2 == log2(.) / sqrt(dh)
-      x = (df * df) * nc2 + x;
-      const f4 y = tM[t] * scale2 + mk4;
-      tS[t] = x;
-      tM[t] = y;
-      mx = fmaxf(mx, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
-      if (ADV) my = fmaxf(my, fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])));
-      shl = fmaxf(shl, fmaxf(fmaxf(mk4[0], mk4[1]), fmaxf(mk4[2], mk4[3])));
-    }
-    mx = quad_max(mx);
-    if (ADV) my = quad_max(my);
-    shl = quad_max(shl);  // row's mask maximum (exp2 domain): 0, or -10000*log2e for a fully masked row
-    f4 zx4 = {0.f, 0.f, 0.f, 0.f}, zy4 = zx4;
-#pragma unroll
-    for (int t = 0; t < NTB; ++t) {
-      const f4 dx = tS[t] - mx, dy = tM[t] - my;
-      f4 e, f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        e[r] = ex2(dx[r]);
-        if (ADV) f[r] = ex2(dy[r]);
-      }
-      tS[t] = e;
-      zx4 += e;
-      if (ADV) {
-        tM[t] = f;
-        zy4 += f;
-      }
-    }
-    const float zx = quad_sum((zx4[0] + zx4[1]) + (zx4[2] + zx4[3]));
-    const float zy = ADV ? quad_sum((zy4[0] + zy4[1]) + (zy4[2] + zy4[3])) : 1.f;
-    const float rzx = fast_rcp(zx), rzy = fast_rcp(zy);
-
-    f4 ca[DT], cc[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      ca[dt] = f4{0.f, 0.f, 0.f, 0.f};
-      cc[dt] = ca[dt];
-    }
-    f4 zu4 = {0.f, 0.f, 0.f, 0.f}, zv4 = zu4, zw4 = zu4;
-
-    // ---- pass 2: dropout, M out, perturbed branch into P.V, exp of the calibrated branch ------------------
-#pragma unroll
-    for (int t = 0; t < NTB; ++t) {
-      // keep one tile's working set live at a time: without the fence the scheduler hoists the RNG and
-      // LDS reads of all tiles to the top and the kernel no longer fits 4 waves per SIMD
-      __builtin_amdgcn_sched_barrier(0);
-      const f4 mb = mask4(t) - shl;
-      f4 sa = {1.f, 1.f, 1.f, 1.f}, sm = sa, nz = {0.f, 0.f, 0.f, 0.f};
-      if (ADV || has_drop) {
-        const RngGroup rg = rng_group(seed_eff, rng_row, (uint32_t)(4 * t + g), P.p_drop, keep_scale);
-        nz = f4{rg.n[0], rg.n[1], rg.n[2], rg.n[3]};
-        if (has_drop) {
-          sa = rg.scale_after;
-          sm = rg.scale_mask;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);  // the RNG's temporaries die here
-      const f4 p = tS[t] * (sa * rzx);  // P = dropout(softmax)   layers.py:735-736
-      tS[t] = p;
-      f4 eu;
-      if (ADV) {
-        const f4 m = tM[t] * (sm * rzy);  // M   layers.py:670-672
-        store_seg(O.attack_mask, t, m);
-        const f4 au = (p * m + nz * (1.0f - m)) * kLog2e + mb;  // layers.py:918-919
-        const f4 a1 = m * (-kLog2e) + kLog2e;                   // exp(1 - M)
-        f4 ex1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          eu[r] = ex2(au[r]);
-          ex1[r] = ex2(a1[r]);
-        }
-        zu4 += eu;
-        __builtin_amdgcn_sched_barrier(0);
-        const f4 av = (p * ex1) * kLog2e + mb;  // layers.py:920-921
-        f4 ev;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ev[r] = ex2(av[r]);
-        zv4 += ev;
-        tM[t] = ev;  // M is dead from here on: keep the unnormalised A_c in its registers
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* vp = Vs + (16 * t + 4 * g + r) * VS + c;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          if (ADV)
-            ca[dt] = mfma16(vp[16 * dt], eu[r], ca[dt]);
-          else
-            cc[dt] = mfma16(vp[16 * dt], p[r], cc[dt]);  // spatial calibrator only: ctx = P.V
-        }
-      }
-    }
-
-    // ---- pass 3: gate combine, final softmax, calibrated branch into P.V ---------------------------------
-    float zu = 1.f, zv = 1.f, zw = 1.f;
-    if (ADV) {
-      zv = quad_sum((zv4[0] + zv4[1]) + (zv4[2] + zv4[3]));
-      const float rzv = fast_rcp(zv);
-#pragma unroll
-      for (int t = 0; t < NTB; ++t) {
-        __builtin_amdgcn_sched_barrier(0);
-        const f4 mb = mask4(t) - shl;
-        const int j0 = 16 * t + 4 * g;
-        // staged logits; key groups past the row end read a clamped (finite) address, their A_g is 0 anyway
-        const f4 gl = *(const f4*)(Gs + (row_ok ? i : 0) * GS + min(j0, GS - 4));
-        const f4 eg = gl * (-kLog2e);
-        f4 gt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gt[r] = fast_rcp(1.0f + ex2(eg[r]));  // sigmoid(gate logits)   layers.py:887
-        const f4 acn = tM[t] * rzv;                                      // A_c
-        const f4 aw = (gt * (tS[t] - acn) + acn) * kLog2e + mb;          // layers.py:888, 925
-        f4 ew;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ew[r] = ex2(aw[r]);
-        zw4 += ew;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* vp = Vs + (16 * t + 4 * g + r) * VS + c;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) cc[dt] = mfma16(vp[16 * dt], ew[r], cc[dt]);
-        }
-      }
-      zu = quad_sum((zu4[0] + zu4[1]) + (zu4[2] + zu4[3]));
-      zw = quad_sum((zw4[0] + zw4[1]) + (zw4[2] + zw4[3]));
-      const float rzu = fast_rcp(zu), rzw = fast_rcp(zw);
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        ca[dt] *= rzu;
-        cc[dt] *= rzw;
-      }
-      for (int t = NTB; t < nT; ++t) store_seg(O.attack_mask, t, f4{0.f, 0.f, 0.f, 0.f});  // skipped tiles
-    }
-
-    if (row_ok) {
-      const uint32_t coff = ((uint32_t)rowbase + i) * H + hoff + 4 * g;  // 32-bit offset from a scalar base
-      float* oc = O.ctx_calibrated + coff;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) *(f4*)(oc + 16 * dt) = cc[dt];
-      if (ADV) {
-        float* oa = O.ctx_attacked + coff;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) *(f4*)(oa + 16 * dt) = ca[dt];
-        if (O.row_stats && g == 0) {
-          // natural-log normalisers, as the backward expects them (acattn_bwd.hip)
-          float* sp = O.row_stats + (bh * L + i) * ACATTN_NSTAT;
-          const float sh = shl * kLn2;
-          *(f4*)sp = f4{(mx + __builtin_amdgcn_logf(zx)) * kLn2, (my + __builtin_amdgcn_logf(zy)) * kLn2,
-                        sh + fast_log(zu), sh + fast_log(zv)};
-          *(f4*)(sp + 4) = f4{sh + fast_log(zw), 0.f, 0.f, 0.f};
-        }
-      }
-    }
-  };
-
+#include "acattn_fwd_body.inc"
   switch (nt) {
     case 1: body(std::integral_constant<int, 1>{}); break;
     case 2: body(std::integral_constant<int, 2>{}); break;
