@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libacattn.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -79,6 +79,8 @@ SYMBOLS = {
     "acattn_dropout_add_layernorm_fwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, C.c_void_p]),
     "acattn_dropout_add_layernorm_bwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, _f, _f, _f, C.c_void_p]),
     "acattn_sum_rows": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "acattn_linear_wgrad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "acattn_linear_wgrad": (C.c_int, [_f, _f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
     "acattn_rng_materialize": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, _f, _f, _f, _f,
                                          C.c_void_p]),
 }

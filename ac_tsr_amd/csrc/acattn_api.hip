@@ -2,6 +2,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "acattn_common.h"
 
 namespace {
@@ -167,6 +169,21 @@ int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_
   if (!x || !out) return fail("x and out must be non-NULL");
   if (batch < 1 || R < 1 || C < 1) return fail("batch, R, C must be positive");
   const int rc = acattn_launch_sum_rows(x, out, batch, R, C, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int64_t acattn_linear_wgrad_workspace_bytes(int64_t M, int32_t K, int32_t N) {
+  if (M < 1 || K < 1 || N < 1) return fail("M, K, N must be positive");
+  return acattn_linear_wgrad_ws_bytes(M, K, N);
+}
+
+int acattn_linear_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, void* workspace, float* dw,
+                        float* db, void* stream) {
+  if (!x || !dy || !dw || !workspace) return fail("x, dy, dw and workspace must be non-NULL");
+  if (M < 1 || K < 1 || N < 1) return fail("M, K, N must be positive");
+  if (M * (int64_t)std::max(K, N) >= (1LL << 40)) return fail("matrix too large");
+  const int rc = acattn_launch_linear_wgrad(x, dy, M, K, N, workspace, dw, db, (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;
 }

@@ -147,3 +147,6 @@ int acattn_launch_ln_bwd(const acattn_ln_problem& p, const float* dy, const floa
                          float* dgb_part, hipStream_t stream);
 int acattn_launch_sum_rows(const float* x, float* out, int batch, int R, int C, hipStream_t stream);
 void acattn_set_error(const char* msg);
+int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N);
+int acattn_launch_linear_wgrad(const float* x, const float* dy, int64_t M, int K, int N, void* ws, float* dw, float* db,
+                               hipStream_t stream);

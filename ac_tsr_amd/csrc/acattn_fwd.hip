@@ -759,11 +759,11 @@ int launch_dh(const acattn_problem& p, const acattn_fwd_out& o, bool full, hipSt
 }  // namespace
 
 int acattn_launch_fwd_fast(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
-int acattn_launch_fwd_pipe(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
+int acattn_launch_fwd_dma(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
 
 int acattn_launch_fwd(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
-  const int rc_pipe = acattn_launch_fwd_pipe(p, o, stream);  // software-pipelined variant of the hot path
-  if (rc_pipe != -100) return rc_pipe;
+  const int rc_dma = acattn_launch_fwd_dma(p, o, stream);  // training hot path, 48 < L <= 64, asynchronous staging
+  if (rc_dma != -100) return rc_dma;
   const int rc_fast = acattn_launch_fwd_fast(p, o, stream);  // training hot path (L <= 64); -100 = not applicable
   if (rc_fast != -100) return rc_fast;
   const bool full = p.adversarial && (!p.two_level || o.after_spatial || o.before_spatial || o.perturbed_attention ||

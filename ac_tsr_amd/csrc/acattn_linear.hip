@@ -1,0 +1,183 @@
+// Weight and bias gradients of y = x W^T + b for tall-skinny activations, gfx950.
+//
+//     dW[N, K] = sum_m dy[m, n] x[m, k],   db[n] = sum_m dy[m, n],   M = B*L rows (25,600 at the benchmark shape)
+//
+// These are the parameter gradients of every projection around the calibrated-attention core (query/key/value,
+// the two attack transforms, dense, the gate, the feed-forward pair: recbole/model/layers.py:687-690, 660-661, 681,
+// 792-794, 863).  The reduction runs over M while the output is at most 256 x 256: a GEMM shape BLAS libraries
+// answer badly (hipBLASLt stream-K: 110-125 us; a batched split-K out of library calls + two reduction launches
+// for the slabs + two for the bias: ~25 us), although the work is one pass over 2 x 6.5 MB.
+//
+// Stage 1 (wgrad_partial_kernel): workgroup (p, block) owns a 64(n) x 64(k) block of dW and every P-th slab of
+// rows.  A wave reads 4 rows x 64 columns of dy and of x with ONE coalesced 16-byte load each (lane 16g+c: row
+// g, columns 4c..4c+3) and feeds them straight into fp32 MFMAs: in v_mfma_f32_16x16x4_f32 lane 16g+c supplies
+// A[c][g] and B[g][c], so register e' of the dy load is the A operand of the n-columns {4i+e'} and register e of
+// the x load is the B operand of the k-columns {4j+e}: 16 MFMAs per 4 rows cover the whole 64 x 64 block with
+// no shuffles and no LDS; the block is simply held in a column-permuted order until the final store.
+// Waves of a workgroup are folded through LDS, the workgroup writes one partial.
+// Stage 2 (wgrad_reduce_kernel): sums the P partials in a fixed order (deterministic, no atomics), undoes the
+// permutation, writes dW and db.
+#include <algorithm>
+
+#include "acattn_common.h"
+
+namespace {
+
+constexpr int kRegs = 64;  // accumulator registers per lane: 16 MFMA tiles x 4
+
+__device__ __forceinline__ f4 load_rows4(const float* base, int64_t row, int64_t M, int ld, int col, int ncols) {
+  // 4 consecutive columns of `row`, zero outside the matrix; rows of a matrix with ld % 4 != 0 are only
+  // dword-aligned, and its last columns must not be read past the row end
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (row < M) {
+    const float* p = base + row * ld + col;
+    if (col + 3 < ncols) {
+      v = *(const f4u*)p;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < ncols) v[e] = p[e];
+    }
+  }
+  return v;
+}
+
+template <int UNROLL>
+__global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const int64_t M, const int K, const int N, const int KB,
+                                                             float* __restrict__ part_w, float* __restrict__ part_b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int blk = blockIdx.y, nb = blk / KB, kb = blk - nb * KB;
+  const int P = gridDim.x;
+  const int ncol = nb * 64 + 4 * c, kcol = kb * 64 + 4 * c;
+
+  f4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  // row groups of 4; wave w of workgroup p takes groups (p * 4 + w) + i * 4P
+  const int64_t stride = (int64_t)P * 4 * 4;
+  for (int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 4; m0 < M; m0 += stride * UNROLL) {
+    f4 xv[UNROLL], gv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {  // all loads of the iteration in flight before the first MFMA
+      const int64_t row = m0 + u * stride + g;
+      xv[u] = load_rows4(x, row, M, K, kcol, K);
+      gv[u] = load_rows4(dy, row, M, N, ncol, N);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      bsum += gv[u];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(gv[u][a], xv[u][b], acc[a][b]);
+    }
+  }
+
+  // fold the 4 waves: [wave][reg][lane] in LDS, thread t sums the 4 copies of 16 (reg, lane) slots
+  __shared__ float red[4 * kRegs * 64];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * kRegs + (a * 4 + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+  __syncthreads();
+  float* pw = part_w + ((size_t)blk * P + blockIdx.x) * (kRegs * 64);
+  for (int s = threadIdx.x; s < kRegs * 64; s += 256)
+    pw[s] = (red[s] + red[kRegs * 64 + s]) + (red[2 * kRegs * 64 + s] + red[3 * kRegs * 64 + s]);
+  if (part_b && kb == 0) {
+    __syncthreads();
+    *(f4*)(red + 4 * threadIdx.x) = bsum;  // [wave][g][c][e]
+    __syncthreads();
+    if (threadIdx.x < 64) {  // column nb*64 + t = 4c + e  ->  c = t >> 2, e = t & 3
+      float s = 0.f;
+#pragma unroll
+      for (int wg = 0; wg < 16; ++wg) s += red[4 * (wg * 16 + (threadIdx.x >> 2)) + (threadIdx.x & 3)];
+      part_b[((size_t)nb * P + blockIdx.x) * 64 + threadIdx.x] = s;
+    }
+  }
+}
+
+// dW[n, k] for n = nb*64 + 16g + 4r + a, k = kb*64 + 4c + b lives at slot ((a*4 + b)*4 + r) * 64 + 16g + c of
+// every partial (D register r of lane 16g+c is D[4g + r][c]; tile (a, b) holds n-columns {4i + a}, k-columns {4j + b}).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part_w,
+                                                            const float* __restrict__ part_b, const int P, const int K,
+                                                            const int N, const int KB, float* __restrict__ dw,
+                                                            float* __restrict__ db) {
+  const int blk = blockIdx.y, nb = blk / KB, kb = blk - nb * KB;
+  // 64 slots per workgroup, 4 threads per slot (each sums every 4th partial), folded through LDS
+  const int sl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int s = blockIdx.x * 64 + sl;  // slot 0..4095
+  const float* pw = part_w + (size_t)blk * P * (kRegs * 64) + s;
+  constexpr size_t PS = kRegs * 64;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int p = q;
+  for (; p + 12 < P; p += 16) {
+    a0 += pw[(size_t)p * PS];
+    a1 += pw[(size_t)(p + 4) * PS];
+    a2 += pw[(size_t)(p + 8) * PS];
+    a3 += pw[(size_t)(p + 12) * PS];
+  }
+  for (; p < P; p += 4) a0 += pw[(size_t)p * PS];
+  __shared__ float red[4][64];
+  red[q][sl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0) {
+    const float v = (red[0][sl] + red[1][sl]) + (red[2][sl] + red[3][sl]);
+    const int reg = s >> 6, lane = s & 63;
+    const int tile = reg >> 2, r = reg & 3, a = tile >> 2, b = tile & 3, g = lane >> 4, c = lane & 15;
+    const int n = nb * 64 + 4 * (4 * g + r) + a, k = kb * 64 + 4 * c + b;
+    if (n < N && k < K) dw[(size_t)n * K + k] = v;
+  }
+  if (db && kb == 0 && blockIdx.x == 0) {
+    __syncthreads();
+    const int nn = nb * 64 + sl;
+    const float* pb = part_b + (size_t)nb * P * 64 + sl;
+    float sb = 0.f;
+    for (int t = q; t < P; t += 4) sb += pb[(size_t)t * 64];
+    red[q][sl] = sb;
+    __syncthreads();
+    if (q == 0 && nn < N) db[nn] = (red[0][sl] + red[1][sl]) + (red[2][sl] + red[3][sl]);
+  }
+}
+
+int pick_partials(int64_t M, int blocks) {
+  // enough workgroups to fill 256 CUs, at least 64 rows per workgroup, at most 256 partials to fold
+  int p = std::max(1, 512 / blocks);
+  p = (int)std::min<int64_t>(p, std::max<int64_t>(1, M / 64));
+  return std::min(p, 256);
+}
+
+}  // namespace
+
+int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N) {
+  const int KB = (K + 63) / 64, NB = (N + 63) / 64;
+  const int P = pick_partials(M, KB * NB);
+  return ((int64_t)KB * NB * P * kRegs * 64 + (int64_t)NB * P * 64) * (int64_t)sizeof(float);
+}
+
+int acattn_launch_linear_wgrad(const float* x, const float* dy, int64_t M, int K, int N, void* ws, float* dw, float* db,
+                               hipStream_t stream) {
+  const int KB = (K + 63) / 64, NB = (N + 63) / 64;
+  const int P = pick_partials(M, KB * NB);
+  float* part_w = (float*)ws;
+  float* part_b = part_w + (size_t)KB * NB * P * kRegs * 64;
+  const int64_t groups_per_wave = (M / 4 + (int64_t)P * 4 - 1) / ((int64_t)P * 4);
+  if (groups_per_wave >= 4)
+    hipLaunchKernelGGL((wgrad_partial_kernel<4>), dim3(P, KB * NB), dim3(256), 0, stream, x, dy, M, K, N, KB, part_w,
+                       db ? part_b : nullptr);
+  else
+    hipLaunchKernelGGL((wgrad_partial_kernel<1>), dim3(P, KB * NB), dim3(256), 0, stream, x, dy, M, K, N, KB, part_w,
+                       db ? part_b : nullptr);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kRegs, KB * NB), dim3(256), 0, stream, part_w, part_b, P, K, N,
+                     KB, dw, db);
+  return (int)hipGetLastError();
+}

@@ -4,10 +4,10 @@ benchmark shape) with a weight gradient that does not fall into a library pothol
 The forward and the input gradient are ordinary GEMMs (hipBLASLt via torch).  The weight gradient
 dW[N,K] = sum_m g[m,n] x[m,k] is a GEMM whose reduction dimension is B*L: on MI355X / ROCm 7.2 hipBLASLt's
 heuristic answers it with a stream-K kernel that takes 110-125 us, rocBLAS takes 25-50 us but is 20x
-slower on the step's one large GEMM (tools/gemm_probe.py, profiles/).  Here the reduction is split into
-S independent slabs, multiplied as ONE batched GEMM ([S, N, M/S] x [S, M/S, K]) and summed -- the textbook
-split-K, expressed with library calls.  Parameters stay ordinary nn.Linear weights (state-dict keys are
-load-bearing, recbole/trainer/trainer.py:672-683).
+slower on the step's one large GEMM (tools/gemm_probe.py, profiles/).  dW and db therefore come from
+acattn_linear_wgrad (csrc/acattn_linear.hip): one pass over x and dy feeding fp32 MFMAs, two launches per layer
+instead of the five of a split-K built from library calls.  Parameters stay ordinary nn.Linear weights
+(state-dict keys are load-bearing, recbole/trainer/trainer.py:672-683).
 """
 from __future__ import annotations
 
@@ -66,15 +66,11 @@ class _SkinnyLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = (g2 @ weight).view_as(x)
         want_params = ctx.is_attack or not _ATTACK_PASS_ONLY
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and want_params
         if ctx.needs_input_grad[1] and want_params:
-            x2 = x.reshape(-1, x.shape[-1])
-            m = x2.shape[0]
-            s = _split(m)
-            if s > 1:
-                gw = _sum_rows(torch.bmm(g2.view(s, m // s, -1).transpose(1, 2), x2.view(s, m // s, -1)), 0)
-            else:
-                gw = g2.t() @ x2
-        if ctx.has_bias and ctx.needs_input_grad[2] and want_params:
+            from .ops import linear_wgrad
+            gw, gb = linear_wgrad(x.reshape(-1, x.shape[-1]), g2, want_b)
+        elif want_b:
             gb = _sum_rows(g2, 0)
         return gx, gw, gb, None
 

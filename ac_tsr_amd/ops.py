@@ -326,3 +326,19 @@ def sum_rows(x: torch.Tensor, dim: int = 0) -> torch.Tensor:
             part = _launch_sum_rows(x, batch * s, R // s, Cn, (batch, s, Cn))
             return _launch_sum_rows(part, batch, s, Cn, out_shape)
     return _launch_sum_rows(x, batch, R, Cn, out_shape)
+
+
+def linear_wgrad(x2: torch.Tensor, g2: torch.Tensor, want_bias: bool):
+    """(dW [N,K], db [N] or None) of y = x W^T + b from x2 [M,K] and dy g2 [M,N] through acattn_linear_wgrad
+    (one pass over both matrices, fp32 MFMA).  No autograd: used inside backward functions."""
+    assert x2.is_cuda and x2.dtype == torch.float32 and g2.dtype == torch.float32 and x2.shape[0] == g2.shape[0]
+    x2, g2 = x2.contiguous(), g2.contiguous()
+    M, K = x2.shape
+    N = g2.shape[1]
+    lib = _lib.load()
+    ws = torch.empty(lib.acattn_linear_wgrad_workspace_bytes(M, K, N) // 4, device=x2.device, dtype=torch.float32)
+    dw = torch.empty(N, K, device=x2.device, dtype=torch.float32)
+    db = torch.empty(N, device=x2.device, dtype=torch.float32) if want_bias else None
+    _lib.check(lib.acattn_linear_wgrad(_ptr(x2), _ptr(g2), M, K, N, _ptr(ws), _ptr(dw), _ptr(db) if want_bias else None,
+                                       _stream()), "linear_wgrad")
+    return dw, db

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 5
+#define ACATTN_ABI_VERSION 6
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -171,6 +171,15 @@ int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy
 /* out[bt, c] = sum_r x[bt, r, c]  (x is [batch, R, C] contiguous).  The reductions of the training step's backward:
  * bias gradients (sum over B*L rows), split-K slabs, per-(b,head) parameter partials, per-head gate gradients. */
 int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_t C, void* stream);
+
+/* Parameter gradients of y = x W^T + b (torch.nn.functional.linear as called for query/key/value, the attack
+ * transforms, dense, the gate and the feed-forward pair: recbole/model/layers.py:687-690, 660-661, 681, 792-794, 863):
+ *   dw[N,K] = sum_m dy[m,n] x[m,k]      db[N] = sum_m dy[m,n]  (db may be NULL)
+ * x [M,K] and dy [M,N] contiguous fp32, M = B*L rows; one pass over both, fp32 MFMA, deterministic two-stage
+ * reduction.  `workspace` is caller-owned scratch of acattn_linear_wgrad_workspace_bytes(M, K, N) bytes. */
+int64_t acattn_linear_wgrad_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int acattn_linear_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, void* workspace, float* dw,
+                        float* db, void* stream);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);

@@ -1,0 +1,54 @@
+"""GPU suite (-m gpu): weight / bias gradients of the tall-skinny linears (acattn_linear_wgrad) against an fp64
+product of the same operands, and the layer-level autograd path (linear.skinny_linear) against torch's own."""
+import pytest
+import torch
+
+from ac_tsr_amd import linear, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("M,K,N", [(25600, 64, 64), (25600, 64, 256), (25600, 256, 64), (25600, 64, 50),
+                                   (37, 64, 50), (1000, 128, 128), (3, 64, 64), (4099, 256, 200), (777, 50, 64)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_linear_wgrad_matches_fp64(M, K, N, bias):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    dw, db = ops.linear_wgrad(x.to(DEV), dy.to(DEV), bias)
+    ref_w = (dy.double().t() @ x.double())
+    ref_b = dy.double().sum(0)
+    # fp32 accumulation of M products of unit-variance terms: error ~ sqrt(M) * eps * |term|
+    tol = 4e-6 * (M ** 0.5) + 1e-5
+    assert dw.shape == (N, K)
+    assert (dw.cpu().double() - ref_w).abs().max() <= tol * max(1.0, ref_w.abs().max().item() / (M ** 0.5))
+    if bias:
+        assert (db.cpu().double() - ref_b).abs().max() <= tol * max(1.0, ref_b.abs().max().item() / (M ** 0.5))
+    else:
+        assert db is None
+
+
+def test_linear_wgrad_is_deterministic():
+    g = torch.Generator().manual_seed(5)
+    x, dy = torch.randn(25600, 64, generator=g).to(DEV), torch.randn(25600, 64, generator=g).to(DEV)
+    a = ops.linear_wgrad(x, dy, True)
+    b = ops.linear_wgrad(x, dy, True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("shape,N", [((512, 50, 64), 64), ((16, 50, 64), 256), ((8, 50, 256), 64), ((4, 50, 64), 50)])
+def test_skinny_linear_autograd_matches_torch(shape, N):
+    g = torch.Generator().manual_seed(N)
+    layer = torch.nn.Linear(shape[-1], N).to(DEV)
+    x = torch.randn(*shape, generator=g).to(DEV)
+    cot = torch.randn(*shape[:-1], N, generator=g).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = linear.skinny_linear(xa, layer)
+    ga = torch.autograd.grad((ya * cot).sum(), [xa, layer.weight, layer.bias])
+    xb = x.clone().requires_grad_(True)
+    yb = layer(xb)
+    gb = torch.autograd.grad((yb * cot).sum(), [xb, layer.weight, layer.bias])
+    assert torch.equal(ya, yb)
+    for got, want in zip(ga, gb):
+        assert (got - want).abs().max() <= 2e-5 * want.abs().max() + 1e-6
