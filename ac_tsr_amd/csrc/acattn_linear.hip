@@ -111,47 +111,56 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
                                                             const int N, const int KB, float* __restrict__ dw,
                                                             float* __restrict__ db) {
   const int blk = blockIdx.y, nb = blk / KB, kb = blk - nb * KB;
-  // 64 slots per workgroup, 4 threads per slot (each sums every 4th partial), folded through LDS
-  const int sl = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int s = blockIdx.x * 64 + sl;  // slot 0..4095
+  // 32 slots per workgroup, 8 threads per slot; a thread sums every 8th partial with 8 loads in flight at a time
+  // (the kernel is a latency chain otherwise: 4 MB spread over few workgroups), folded through LDS
+  const int sl = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int s = blockIdx.x * 32 + sl;  // slot 0..4095
   const float* pw = part_w + (size_t)blk * P * (kRegs * 64) + s;
   constexpr size_t PS = kRegs * 64;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
   int p = q;
-  for (; p + 12 < P; p += 16) {
-    a0 += pw[(size_t)p * PS];
-    a1 += pw[(size_t)(p + 4) * PS];
-    a2 += pw[(size_t)(p + 8) * PS];
-    a3 += pw[(size_t)(p + 12) * PS];
+  for (; p + 56 < P; p += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += pw[(size_t)(p + 8 * u) * PS];
   }
-  for (; p < P; p += 4) a0 += pw[(size_t)p * PS];
-  __shared__ float red[4][64];
-  red[q][sl] = (a0 + a1) + (a2 + a3);
+  for (; p < P; p += 8) a[0] += pw[(size_t)p * PS];
+  __shared__ float red[8][32];
+  red[q][sl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   if (q == 0) {
-    const float v = (red[0][sl] + red[1][sl]) + (red[2][sl] + red[3][sl]);
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += red[u][sl];
     const int reg = s >> 6, lane = s & 63;
-    const int tile = reg >> 2, r = reg & 3, a = tile >> 2, b = tile & 3, g = lane >> 4, c = lane & 15;
-    const int n = nb * 64 + 4 * (4 * g + r) + a, k = kb * 64 + 4 * c + b;
+    const int tile = reg >> 2, r = reg & 3, aa = tile >> 2, bb = tile & 3, g = lane >> 4, c = lane & 15;
+    const int n = nb * 64 + 4 * (4 * g + r) + aa, k = kb * 64 + 4 * c + bb;
     if (n < N && k < K) dw[(size_t)n * K + k] = v;
   }
-  if (db && kb == 0 && blockIdx.x == 0) {
+  if (db && kb == 0 && blockIdx.x < 2) {  // 2 workgroups x 32 columns
     __syncthreads();
-    const int nn = nb * 64 + sl;
-    const float* pb = part_b + (size_t)nb * P * 64 + sl;
+    const int col = blockIdx.x * 32 + sl, nn = nb * 64 + col;
+    const float* pb = part_b + (size_t)nb * P * 64 + col;
     float sb = 0.f;
-    for (int t = q; t < P; t += 4) sb += pb[(size_t)t * 64];
+    for (int t = q; t < P; t += 8) sb += pb[(size_t)t * 64];
     red[q][sl] = sb;
     __syncthreads();
-    if (q == 0 && nn < N) db[nn] = (red[0][sl] + red[1][sl]) + (red[2][sl] + red[3][sl]);
+    if (q == 0 && nn < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += red[u][sl];
+      db[nn] = v;
+    }
   }
 }
 
 int pick_partials(int64_t M, int blocks) {
-  // enough workgroups to fill 256 CUs, at least 64 rows per workgroup, at most 256 partials to fold
-  int p = std::max(1, 512 / blocks);
-  p = (int)std::min<int64_t>(p, std::max<int64_t>(1, M / 64));
-  return std::min(p, 256);
+  // Measured on MI355X at M = 25,600 (tools/gpu_wgrad.sh): stage 1 takes ~10 us whether 128 or 256 workgroups
+  // share a 64 x 64 block, stage 2 grows with the number of partials it folds -> few partials, but never fewer
+  // than 64 workgroups per block and never less than 64 rows per workgroup.
+  int p = std::max(64, 128 / blocks);
+  return (int)std::min<int64_t>(p, std::max<int64_t>(1, M / 64));
 }
 
 }  // namespace
@@ -168,16 +177,19 @@ int acattn_launch_linear_wgrad(const float* x, const float* dy, int64_t M, int K
   const int P = pick_partials(M, KB * NB);
   float* part_w = (float*)ws;
   float* part_b = part_w + (size_t)KB * NB * P * kRegs * 64;
-  const int64_t groups_per_wave = (M / 4 + (int64_t)P * 4 - 1) / ((int64_t)P * 4);
-  if (groups_per_wave >= 4)
-    hipLaunchKernelGGL((wgrad_partial_kernel<4>), dim3(P, KB * NB), dim3(256), 0, stream, x, dy, M, K, N, KB, part_w,
-                       db ? part_b : nullptr);
+  // a wave's loads are all issued before its first MFMA when they fit (one HBM latency instead of several)
+  const int64_t groups_per_wave = ((M + 3) / 4 + (int64_t)P * 4 - 1) / ((int64_t)P * 4);
+  const dim3 grid(P, KB * NB);
+  float* pb = db ? part_b : nullptr;
+  if (groups_per_wave > 4)
+    hipLaunchKernelGGL((wgrad_partial_kernel<7>), grid, dim3(256), 0, stream, x, dy, M, K, N, KB, part_w, pb);
+  else if (groups_per_wave >= 4)
+    hipLaunchKernelGGL((wgrad_partial_kernel<4>), grid, dim3(256), 0, stream, x, dy, M, K, N, KB, part_w, pb);
   else
-    hipLaunchKernelGGL((wgrad_partial_kernel<1>), dim3(P, KB * NB), dim3(256), 0, stream, x, dy, M, K, N, KB, part_w,
-                       db ? part_b : nullptr);
+    hipLaunchKernelGGL((wgrad_partial_kernel<1>), grid, dim3(256), 0, stream, x, dy, M, K, N, KB, part_w, pb);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kRegs, KB * NB), dim3(256), 0, stream, part_w, part_b, P, K, N,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kRegs * 2, KB * NB), dim3(256), 0, stream, part_w, part_b, P, K, N,
                      KB, dw, db);
   return (int)hipGetLastError();
 }
