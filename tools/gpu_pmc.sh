@@ -16,18 +16,4 @@ pass sq3 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_BRA
 pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_MFMA || exit 1
 pass fetch FETCH_SIZE || exit 1
 pass write WRITE_SIZE GRBM_GUI_ACTIVE || exit 1
-python3 - <<PY
-import csv, glob, collections
-for tag in ("sq1","sq2","sq3","fetch","write"):
-    files = glob.glob("$R/gpurun_out/$name/%s/**/*counter_collection.csv" % tag, recursive=True)
-    if not files:
-        print(tag, "no counter file"); continue
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for row in csv.DictReader(open(files[0])):
-        k = row["Kernel_Name"]
-        if "acattn" not in k: continue
-        short = "fast_adv" if "fast_kernel" in k and "true" in k else ("fast_spatial" if "fast_kernel" in k else k[:60])
-        acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k, d in acc.items():
-        print(tag, k, {c: round(sum(v)/len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
-PY
+python3 $R/tools/pmc_to_json.py $R/gpurun_out/$name $R/gpurun_out/$name/pmc.json
