@@ -63,5 +63,10 @@ def full_sort_cross_entropy(output: torch.Tensor, table: torch.Tensor, target: t
     return _FullSortCE.apply(output.contiguous(), table, target).mean()
 
 
+def full_sort_cross_entropy_rows(output: torch.Tensor, table: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """Per-row losses `CrossEntropyLoss(reduction='none')(output @ table.T, target)` (acbert4rec.py:201-206)."""
+    return _FullSortCE.apply(output.contiguous(), table, target)
+
+
 def supported(hidden_size: int) -> bool:
     return hidden_size in (64, 128)

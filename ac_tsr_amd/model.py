@@ -8,6 +8,7 @@ state-dict keys.  `config[k]` may be any mapping; missing keys read as None like
 """
 from __future__ import annotations
 
+import random
 from enum import Enum
 
 import torch
@@ -195,6 +196,206 @@ class ACSASRec(SequentialRecommender):
         _, calibrated_output, _ = self.forward(item_seq, item_seq_len, _rnds=_rnds)
         scores = torch.matmul(calibrated_output, self.item_embedding.weight.transpose(0, 1))
         return None, scores
+
+
+class AcBERT4Rec(SequentialRecommender):
+    """recbole/model/sequential_recommender/acbert4rec.py:11-267: cloze (masked-item) training over the same
+    calibrated encoder with a bidirectional mask.
+
+    Same constructor, methods, return values and state-dict keys.  Two additions, both opt-in through config keys
+    the reference does not know: `cloze_on_device` builds the masked batch with tensor ops on the device (the
+    reference walks Python lists on the host, acbert4rec.py:105-150) and `gate_seq_length` as in ACSASRec.
+    Reference behaviour kept on purpose: `masked_index > 0` marks real slots, so a masked FIRST position does not
+    contribute to the loss (acbert4rec.py:226); evaluation appends a mask token (L+1 columns), which the gate
+    (width pinned to L) and the position table (L rows) cannot take (acbert4rec.py:47,152-160)."""
+
+    bidirectional = True
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.n_layers = config['n_layers']
+        self.n_heads = config['n_heads']
+        self.hidden_size = config['hidden_size']
+        self.inner_size = config['inner_size']
+        self.hidden_dropout_prob = config['hidden_dropout_prob']
+        self.attn_dropout_prob = config['attn_dropout_prob']
+        self.hidden_act = config['hidden_act']
+        self.layer_norm_eps = config['layer_norm_eps']
+        self.mask_ratio = config['mask_ratio']
+        self.loss_type = config['loss_type']
+        self.initializer_range = config['initializer_range']
+        self.combine_option = config['combine_option']
+        self.rich_calibrated_combine = _cfg(config, 'rich_calibrated_combine')
+        self.two_level = _cfg(config, 'two_level')
+        self.use_position_embedding = _cfg(config, 'use_position_embedding')
+        self.use_order = _cfg(config, 'use_order')
+        self.use_distance = _cfg(config, 'use_distance')
+        self.trainable_mask_loss_weight = _cfg(config, 'trainable_mask_loss_weight')
+        self.cloze_on_device = bool(_cfg(config, 'cloze_on_device', False))
+        seq_length = _cfg(config, 'gate_seq_length', 50)
+
+        self.mask_token = self.n_items
+        self.mask_item_length = int(self.mask_ratio * self.max_seq_length)
+        self.item_embedding = nn.Embedding(self.n_items + 1, self.hidden_size, padding_idx=0)  # + the mask token
+        if self.use_position_embedding:
+            self.position_embedding = nn.Embedding(self.max_seq_length, self.hidden_size)
+        self.trm_encoder = AttackRTransformerEncoder(
+            n_layers=self.n_layers, n_heads=self.n_heads, hidden_size=self.hidden_size, inner_size=self.inner_size,
+            hidden_dropout_prob=self.hidden_dropout_prob, attn_dropout_prob=self.attn_dropout_prob,
+            hidden_act=self.hidden_act, layer_norm_eps=self.layer_norm_eps, combine_option=self.combine_option,
+            use_order=self.use_order, use_distance=self.use_distance, two_level=self.two_level,
+            rich_calibrated_combine=self.rich_calibrated_combine, seq_length=seq_length)
+        self.LayerNorm = nn.LayerNorm(self.hidden_size, eps=self.layer_norm_eps)
+        self.dropout = nn.Dropout(self.hidden_dropout_prob)
+        if self.trainable_mask_loss_weight:
+            self.mask_loss_weight = nn.Parameter(torch.FloatTensor([0.3]), requires_grad=True)
+        else:
+            self.mask_loss_weight = config['mask_loss_weight']
+        if self.loss_type not in ('BPR', 'CE'):
+            raise AssertionError("Make sure 'loss_type' in ['BPR', 'CE']!")
+        self.apply(self._init_weights)
+
+    _init_weights = ACSASRec._init_weights
+
+    # ---- cloze reconstruction ---------------------------------------------------------------------------------
+    def _neg_sample(self, item_set):
+        item = random.randint(1, self.n_items - 1)
+        while item in item_set:
+            item = random.randint(1, self.n_items - 1)
+        return item
+
+    def _padding_sequence(self, sequence, max_length):
+        return ([0] * (max_length - len(sequence)) + sequence)[-max_length:]
+
+    def reconstruct_train_data(self, item_seq):
+        """Masked sequence, positives, negatives and masked positions (acbert4rec.py:105-150).  The host flavour
+        draws from Python's `random` in the reference's order, so a seeded `random` gives the reference's batch."""
+        if self.cloze_on_device:
+            return self._reconstruct_train_data_device(item_seq)
+        rows = item_seq.cpu().tolist()
+        masked_rows, pos_rows, neg_rows, idx_rows = [], [], [], []
+        for row in rows:
+            masked, pos, neg, idx = list(row), [], [], []
+            for j, item in enumerate(row):
+                if item == 0:  # right-padded: the sequence has ended
+                    break
+                if random.random() < self.mask_ratio:
+                    pos.append(item)
+                    neg.append(self._neg_sample(row))
+                    masked[j] = self.mask_token
+                    idx.append(j)
+            masked_rows.append(masked)
+            for dst, src in ((pos_rows, pos), (neg_rows, neg), (idx_rows, idx)):
+                dst.append(self._padding_sequence(src, self.mask_item_length))
+        to = lambda v: torch.tensor(v, dtype=torch.long, device=item_seq.device).view(len(rows), -1)
+        return to(masked_rows), to(pos_rows), to(neg_rows), to(idx_rows)
+
+    def _reconstruct_train_data_device(self, item_seq, generator=None):
+        """The same batch distribution built with tensor ops on the device: no host round trip, no
+        synchronisation (usable inside a captured graph).  A masked item keeps its order; the short lists are
+        right-aligned and keep the LAST mask_item_length entries, like `_padding_sequence`."""
+        B, L = item_seq.shape
+        ml, dev = self.mask_item_length, item_seq.device
+        real = (item_seq != 0).long().cumprod(dim=1).bool()  # the reference stops at the first padding
+        m = real & (torch.rand(B, L, device=dev, generator=generator) < self.mask_ratio)
+        masked_seq = torch.where(m, torch.full_like(item_seq, self.mask_token), item_seq)
+        count = m.sum(dim=1, keepdim=True)
+        slot = ml - count + (m.long().cumsum(dim=1) - 1)
+        slot = torch.where(m & (slot >= 0), slot, torch.full_like(slot, ml))  # column ml = dropped
+        # negatives: uniform over the catalogue, redrawn a few times where they hit an item of the sequence
+        neg = torch.randint(1, self.n_items, (B, L), device=dev, generator=generator)
+        for _ in range(8):
+            clash = (neg.unsqueeze(2) == item_seq.unsqueeze(1)).any(dim=2)
+            neg = torch.where(clash, torch.randint(1, self.n_items, (B, L), device=dev, generator=generator), neg)
+        position = torch.arange(L, device=dev).expand(B, L)
+        out = []
+        for src in (item_seq, neg, position):
+            buf = torch.zeros(B, ml + 1, dtype=torch.long, device=dev)
+            out.append(buf.scatter_(1, slot, src)[:, :ml])
+        pos_items, neg_items, masked_index = out
+        return masked_seq, pos_items, neg_items, masked_index
+
+    def reconstruct_test_data(self, item_seq, item_seq_len):
+        """One more column, the mask token right after the last item (acbert4rec.py:152-160)."""
+        pad = torch.zeros(item_seq.size(0), 1, dtype=torch.long, device=item_seq.device)
+        item_seq = torch.cat((item_seq, pad), dim=-1)
+        return item_seq.scatter(1, item_seq_len.view(-1, 1), self.mask_token)
+
+    # ---- model ------------------------------------------------------------------------------------------------------
+    def forward(self, item_seq, _rnds=None, _keep_emb=None):
+        item_emb = embedding_lookup(item_seq, self.item_embedding)
+        input_emb = item_emb
+        if self.use_position_embedding:
+            if item_seq.size(1) > self.position_embedding.num_embeddings:
+                raise IndexError("index out of range in self")  # what nn.Embedding raises on the host
+            position_ids = torch.arange(item_seq.size(1), dtype=torch.long, device=item_seq.device)
+            input_emb = item_emb + self.position_embedding(position_ids).unsqueeze(0)
+        input_emb = self.LayerNorm(input_emb)
+        if _keep_emb is not None:
+            input_emb = input_emb * (_keep_emb.to(input_emb.dtype) / (1.0 - self.dropout.p))
+        else:
+            input_emb = self.dropout(input_emb)
+        mask = self.get_structured_mask(item_seq, bidirectional=True)
+        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
+        attacked_output, calibrated_output = trm_output[0][-1]
+        return attacked_output, calibrated_output, trm_output[1]
+
+    def multi_hot_embed(self, masked_index, max_length):
+        """acbert4rec.py:180-199 (kept for callers; calculate_loss gathers the rows directly)."""
+        masked_index = masked_index.view(-1)
+        multi_hot = torch.zeros(masked_index.size(0), max_length, device=masked_index.device)
+        multi_hot[torch.arange(masked_index.size(0)), masked_index] = 1
+        return multi_hot
+
+    def _cal_loss(self, seq_output, pos_items, targets):
+        """CE over the catalogue without the mask-token row, averaged over the real masked slots
+        (acbert4rec.py:201-209)."""
+        table = self.item_embedding.weight[:self.n_items]
+        rows = seq_output.reshape(-1, seq_output.size(-1))
+        if rows.is_cuda and ce.supported(self.hidden_size) and torch.is_grad_enabled():
+            per_slot = ce.full_sort_cross_entropy_rows(rows, table, pos_items.reshape(-1))
+        else:
+            per_slot = nn.functional.cross_entropy(full_sort_scores(rows, table), pos_items.reshape(-1), reduction='none')
+        return torch.sum(per_slot * targets) / torch.sum(targets)
+
+    def calculate_loss(self, interaction, _cloze=None, _rnds=None, _keep_emb=None):
+        item_seq = interaction[self.ITEM_SEQ]
+        masked_item_seq, pos_items, neg_items, masked_index = _cloze or self.reconstruct_train_data(item_seq)
+        attacked_output, calibrated_output, all_attack_masks = self.forward(masked_item_seq, _rnds=_rnds,
+                                                                            _keep_emb=_keep_emb)
+        # the reference multiplies by a one-hot matrix (acbert4rec.py:219-225): a row gather, exactly
+        index = masked_index.unsqueeze(-1).expand(-1, -1, attacked_output.size(-1))
+        attacked_seq_output = attacked_output.gather(1, index)
+        calibrated_seq_output = calibrated_output.gather(1, index)
+        targets = (masked_index > 0).float().view(-1)
+        if self.loss_type == 'BPR':
+            raise NotImplementedError("the reference computes only the CE loss here (acbert4rec.py:201-209)")
+        attacked_loss = -self._cal_loss(attacked_seq_output, pos_items, targets)
+        mask_penalty = torch.mean(torch.stack([torch.norm(1 - m, p=2) for m in all_attack_masks], dim=0))
+        if self.trainable_mask_loss_weight:
+            final_attacked_loss = attacked_loss + mask_penalty * self.mask_loss_weight[0]
+        else:
+            final_attacked_loss = attacked_loss + mask_penalty * self.mask_loss_weight
+        calibrated_loss = self._cal_loss(calibrated_seq_output, pos_items, targets)
+        return final_attacked_loss, calibrated_loss
+
+    def predict(self, interaction):
+        item_seq = self.reconstruct_test_data(interaction[self.ITEM_SEQ], interaction[self.ITEM_SEQ_LEN])
+        item_seq_len = interaction[self.ITEM_SEQ_LEN]
+        attacked_output, calibrated_output, _ = self.forward(item_seq)
+        test_item_emb = self.item_embedding(interaction[self.ITEM_ID])
+        attacked_scores = torch.mul(self.gather_indexes(attacked_output, item_seq_len), test_item_emb).sum(dim=1)
+        scores = torch.mul(self.gather_indexes(calibrated_output, item_seq_len), test_item_emb).sum(dim=1)
+        return attacked_scores, scores
+
+    def full_sort_predict(self, interaction, _rnds=None):
+        item_seq_len = interaction[self.ITEM_SEQ_LEN]
+        item_seq = self.reconstruct_test_data(interaction[self.ITEM_SEQ], item_seq_len)
+        attacked_output, calibrated_output, _ = self.forward(item_seq, _rnds=_rnds)
+        test_items_emb = self.item_embedding.weight[:self.n_items]  # without the mask token
+        attacked_scores = torch.matmul(self.gather_indexes(attacked_output, item_seq_len), test_items_emb.transpose(0, 1))
+        scores = torch.matmul(self.gather_indexes(calibrated_output, item_seq_len), test_items_emb.transpose(0, 1))
+        return attacked_scores, scores
 
 
 class _BPRLoss(nn.Module):

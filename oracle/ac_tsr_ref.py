@@ -401,6 +401,122 @@ def two_pass_grads(batch, P: Dict[str, Tensor], cfg: ModelCfg, train: bool = Tru
 
 
 # ----------------------------------------------------------------------------------------------
+# recbole/model/sequential_recommender/acbert4rec.py  AcBERT4Rec (cloze training over the same encoder)
+# ----------------------------------------------------------------------------------------------
+def cloze_mask_host(item_seq: Tensor, mask_ratio: float, mask_token: int, n_items: int, mask_item_length: int,
+                    rng=None):
+    """AcBERT4Rec.reconstruct_train_data (acbert4rec.py:105-150): walks every sequence up to its first padding,
+    masks an item with probability mask_ratio and draws one negative per masked item.  Consumes Python's `random`
+    stream call for call like the reference (one random() per real item, then randint() until the draw is not in
+    the sequence), so seeding `random` reproduces its output.  Returns (masked_seq [B,L], pos [B,ml], neg [B,ml],
+    masked_index [B,ml]); the three short lists are LEFT-padded with zeros and keep their LAST ml entries
+    (acbert4rec.py:98-102)."""
+    import random as _random
+    rng = rng or _random
+    rows = item_seq.cpu().tolist()
+    masked_rows, pos_rows, neg_rows, idx_rows = [], [], [], []
+
+    def fit(values):
+        return ([0] * (mask_item_length - len(values)) + values)[-mask_item_length:] if mask_item_length > 0 else []
+
+    for row in rows:
+        masked = list(row)
+        pos, neg, idx = [], [], []
+        for j, item in enumerate(row):
+            if item == 0:
+                break
+            if rng.random() < mask_ratio:
+                draw = rng.randint(1, n_items - 1)
+                while draw in row:
+                    draw = rng.randint(1, n_items - 1)
+                pos.append(item)
+                neg.append(draw)
+                idx.append(j)
+                masked[j] = mask_token
+        masked_rows.append(masked)
+        pos_rows.append(fit(pos))
+        neg_rows.append(fit(neg))
+        idx_rows.append(fit(idx))
+    as_t = lambda v: torch.tensor(v, dtype=torch.long).view(len(rows), -1)
+    return as_t(masked_rows), as_t(pos_rows), as_t(neg_rows), as_t(idx_rows)
+
+
+def bert_forward(item_seq: Tensor, P: Dict[str, Tensor], cfg: ModelCfg, train: bool = False, rnds=None,
+                 keep_emb: Optional[Tensor] = None, materialize: bool = True):
+    """AcBERT4Rec.forward (acbert4rec.py:162-178) -> (attacked [B,L,H], calibrated [B,L,H], list[M])."""
+    emb = F.embedding(item_seq, P["item_embedding.weight"])
+    if cfg.use_position_embedding:
+        pos = torch.arange(item_seq.size(1), dtype=torch.long)
+        emb = emb + F.embedding(pos, P["position_embedding.weight"]).unsqueeze(0)
+    H = emb.shape[-1]
+    emb = F.layer_norm(emb, (H,), P["LayerNorm.weight"], P["LayerNorm.bias"], cfg.enc.layer_norm_eps)
+    if train and keep_emb is None and rnds is None:
+        keep_emb = torch.empty(emb.shape).bernoulli_(1.0 - cfg.enc.hidden_dropout_prob)
+    emb = _drop(emb, keep_emb, cfg.enc.hidden_dropout_prob)
+    mask = attention_mask(item_seq, bidirectional=True)
+    outs, masks, _ = encoder_forward(emb, mask, P, cfg.enc, rnds, train, materialize, prefix="trm_encoder.layer.")
+    att, cal = outs[-1]
+    return att, cal, masks
+
+
+def bert_masked_ce(seq_output: Tensor, pos_items: Tensor, targets: Tensor, P: Dict[str, Tensor], cfg: ModelCfg) -> Tensor:
+    """AcBERT4Rec._cal_loss (acbert4rec.py:201-209): CE over the catalogue WITHOUT the mask-token row, averaged over
+    the real (non-padding) masked slots."""
+    E = P["item_embedding.weight"][:cfg.n_items]
+    logits = seq_output @ E.t()
+    per_slot = F.cross_entropy(logits.view(-1, E.size(0)), pos_items.view(-1), reduction="none")
+    return torch.sum(per_slot * targets) / torch.sum(targets)
+
+
+def bert_calculate_loss(masked_seq: Tensor, pos_items: Tensor, masked_index: Tensor, P: Dict[str, Tensor],
+                        cfg: ModelCfg, train: bool = True, rnds=None, keep_emb=None, materialize: bool = True):
+    """AcBERT4Rec.calculate_loss after the cloze reconstruction (acbert4rec.py:215-240): the hidden rows at the
+    masked positions are picked with the reference's multi-hot bmm (acbert4rec.py:180-199, 219-225)."""
+    att, cal, masks = bert_forward(masked_seq, P, cfg, train, rnds, keep_emb, materialize)
+    B, ml = masked_index.shape
+    multi_hot = torch.zeros(B * ml, masked_seq.size(-1))
+    multi_hot[torch.arange(B * ml), masked_index.view(-1)] = 1
+    multi_hot = multi_hot.view(B, ml, -1)
+    att_rows, cal_rows = torch.bmm(multi_hot, att), torch.bmm(multi_hot, cal)
+    targets = (masked_index > 0).float().view(-1)  # (index 0 doubles as the padding marker, as in the reference)
+    attacked_loss = -bert_masked_ce(att_rows, pos_items, targets, P, cfg)
+    penalty = torch.stack([torch.norm(1 - M, p=2) for M in masks]).mean()
+    w = P["mask_loss_weight"][0] if cfg.trainable_mask_loss_weight else cfg.mask_loss_weight
+    return attacked_loss + penalty * w, bert_masked_ce(cal_rows, pos_items, targets, P, cfg)
+
+
+def bert_two_pass_grads(masked_seq, pos_items, masked_index, P: Dict[str, Tensor], cfg: ModelCfg, train: bool = True,
+                        rnds=None, keep_emb=None, materialize: bool = True):
+    """two_pass_grads for AcBERT4Rec (same trainer protocol, recbole/trainer/trainer.py:672-686)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    att_loss, cal_loss = bert_calculate_loss(masked_seq, pos_items, masked_index, leaves, cfg, train, rnds, keep_emb,
+                                             materialize)
+    names = list(leaves)
+    g_cal = torch.autograd.grad(cal_loss, [leaves[n] for n in names], retain_graph=True, allow_unused=True)
+    g_att = torch.autograd.grad(att_loss, [leaves[n] for n in names], allow_unused=True)
+    grads = {}
+    for n, gc, ga in zip(names, g_cal, g_att):
+        g = ga if is_attack_param(n) else gc
+        grads[n] = torch.zeros_like(P[n]) if g is None else g
+    return att_loss.detach(), cal_loss.detach(), grads
+
+
+def bert_append_mask_token(item_seq: Tensor, item_seq_len: Tensor, mask_token: int) -> Tensor:
+    """AcBERT4Rec.reconstruct_test_data (acbert4rec.py:152-160): one more column, mask token right after the last item."""
+    out = torch.cat((item_seq, torch.zeros(item_seq.size(0), 1, dtype=torch.long)), dim=-1)
+    out[torch.arange(item_seq.size(0)), item_seq_len] = mask_token
+    return out
+
+
+def bert_full_sort_predict(item_seq: Tensor, item_seq_len: Tensor, P: Dict[str, Tensor], cfg: ModelCfg, rnds=None):
+    """AcBERT4Rec.full_sort_predict (acbert4rec.py:257-267) -> (attacked_scores, scores), [B, n_items] each."""
+    seq = bert_append_mask_token(item_seq, item_seq_len, cfg.n_items)
+    att, cal, _ = bert_forward(seq, P, cfg, False, rnds)
+    E = P["item_embedding.weight"][:cfg.n_items]
+    return gather_indexes(att, item_seq_len) @ E.t(), gather_indexes(cal, item_seq_len) @ E.t()
+
+
+# ----------------------------------------------------------------------------------------------
 # The attention core at the projected-tensor boundary (what the HIP kernel computes), expressed
 # with the same reference ops.  Used by tests to check the C-ABI entry points directly.
 # ----------------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ sys.modules.setdefault("torch.utils.tensorboard", _tb)
 
 from recbole.model.layers import AttackRTransformerEncoder  # noqa: E402  (the reference)
 from recbole.model.sequential_recommender.acsasrec import ACSASRec  # noqa: E402
+from recbole.model.sequential_recommender.acbert4rec import AcBERT4Rec  # noqa: E402
 
 from oracle import ac_tsr_ref as O  # noqa: E402
 
@@ -247,6 +248,103 @@ def model_case(name, *, B, L, H, h, inner, n_layers, n_items, combine="gate", si
     save(name, arr)
 
 
+def bert_case(name, *, B, L, H, h, inner, n_layers, n_items, combine="gate", sigma=0.02, seed=0, mask_ratio=0.2,
+              mask_loss_weight=0.03, with_scores=False, use_pos=True):
+    """AcBERT4Rec (acbert4rec.py): the cloze reconstruction under a seeded `random`, the two losses and the two-pass
+    gradients in eval mode (the only RNG consumers are then `random` for the cloze and one randn per layer), and --
+    for combine options that accept L+1 columns -- the full-sort scores."""
+    import random
+    print(f"[bert] {name}")
+    gen = torch.Generator().manual_seed(seed)
+    cfg = Cfg(n_layers=n_layers, n_heads=h, hidden_size=H, inner_size=inner, hidden_dropout_prob=0.5,
+              attn_dropout_prob=0.5, hidden_act="gelu", layer_norm_eps=1e-12, initializer_range=0.02, loss_type="CE",
+              combine_option=combine, rich_calibrated_combine="none", two_level=True, use_position_embedding=use_pos,
+              use_order=True, use_distance=True, trainable_mask_loss_weight=False, mask_loss_weight=mask_loss_weight,
+              mask_ratio=mask_ratio, USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", LIST_SUFFIX="_list",
+              ITEM_LIST_LENGTH_FIELD="item_length", NEG_PREFIX="neg_", MAX_ITEM_LIST_LENGTH=L, device="cpu")
+    torch.manual_seed(seed)
+    model = AcBERT4Rec(cfg, FakeDataset(n_items))
+    if sigma != 0.02:
+        reinit(model, sigma, gen)
+    lens = [int(v) for v in torch.randint(2, L + 1, (B,), generator=gen)]
+    lens[0], lens[1] = L, 2
+    item_seq = make_item_seq(B, L, n_items, lens, gen)
+    item_len = torch.tensor(lens, dtype=torch.long)
+    ecfg = O.EncoderCfg(n_layers=n_layers, n_heads=h, hidden_size=H, inner_size=inner, combine_option=combine,
+                        rich_calibrated_combine="none", seq_length=50)
+    mcfg = O.ModelCfg(enc=ecfg, n_items=n_items, max_seq_length=L, mask_loss_weight=mask_loss_weight,
+                      use_position_embedding=use_pos, bidirectional=True)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.eval()
+
+    # -- cloze reconstruction: reference vs restatement under the same `random` seed ---------------
+    random.seed(seed + 3)
+    masked, pos, neg, idx = model.reconstruct_train_data(item_seq)
+    random.seed(seed + 3)
+    o_masked, o_pos, o_neg, o_idx = O.cloze_mask_host(item_seq, mask_ratio, n_items, n_items, int(mask_ratio * L))
+    for a, b_ in ((masked, o_masked), (pos, o_pos), (neg, o_neg), (idx, o_idx)):
+        assert torch.equal(a, b_), "cloze reconstruction differs"
+    assert (masked == n_items).any()
+
+    arr = {"in.item_id_list": item_seq, "in.item_length": item_len, "in.random_seed": seed + 3,
+           "in.masked_seq": masked, "in.pos_items": pos, "in.neg_items": neg, "in.masked_index": idx,
+           "meta.cfg": np.array([n_layers, h, H, inner, L, n_items]), "meta.combine": combine,
+           "meta.mask_ratio": mask_ratio, "meta.mask_loss_weight": mask_loss_weight, "meta.use_pos": int(use_pos)}
+    for k, v in P.items():
+        arr["p." + k] = v
+
+    # -- two-pass trainer protocol on calculate_loss ------------------------------------------------
+    model.zero_grad()
+    random.seed(seed + 3)
+    torch.manual_seed(seed + 11)
+    att_loss, cal_loss = model.calculate_loss({"item_id_list": item_seq})
+    for n, prm in model.named_parameters():
+        prm.requires_grad = not O.is_attack_param(n)
+    cal_loss.backward(retain_graph=True)
+    for n, prm in model.named_parameters():
+        prm.requires_grad = O.is_attack_param(n)
+    att_loss.backward()
+    for n, prm in model.named_parameters():
+        prm.requires_grad = True
+    ref_grads = {n: (prm.grad.detach().clone() if prm.grad is not None else torch.zeros_like(prm))
+                 for n, prm in model.named_parameters()}
+    torch.manual_seed(seed + 11)
+    rnds = [O.draw_layer_randomness((B, h, L, L), (B, L, H), ecfg, False) for _ in range(n_layers)]
+    o_att, o_cal, o_grads = O.bert_two_pass_grads(masked, pos, idx, P, mcfg, False, rnds)
+    print(f"  losses: ref ({att_loss.item():.6f}, {cal_loss.item():.6f})  restated ({o_att.item():.6f}, {o_cal.item():.6f})")
+    check(name + ".att_loss", o_att, att_loss.detach(), 2e-5)
+    check(name + ".cal_loss", o_cal, cal_loss.detach(), 2e-5)
+    worst = 0.0
+    for n, g in ref_grads.items():
+        scale = max(g.abs().max().item(), 1e-6)
+        worst = max(worst, check(name + ".grad." + n, o_grads[n] / scale, g / scale, 2e-3))
+    print(f"  grads: worst relative-to-max diff {worst:.3g}")
+    arr["out.att_loss"] = att_loss.detach()
+    arr["out.cal_loss"] = cal_loss.detach()
+    for n, g in ref_grads.items():
+        arr["grad." + n] = g
+    for i, r in enumerate(rnds):
+        arr[f"in.noise.{i}"] = r.noise
+
+    # -- full-sort scores (L + 1 columns: impossible with the gate, whose width is pinned to L, and with the
+    #    position embedding, which has only L rows: acbert4rec.py:47,152-160) ----------------------------
+    if with_scores:
+        torch.manual_seed(seed + 7)
+        with torch.no_grad():
+            att_scores, scores = model.full_sort_predict({"item_id_list": item_seq, "item_length": item_len})
+        torch.manual_seed(seed + 7)
+        rn = [O.draw_layer_randomness((B, h, L + 1, L + 1), (B, L + 1, H), ecfg, False) for _ in range(n_layers)]
+        with torch.no_grad():
+            o_as, o_s = O.bert_full_sort_predict(item_seq, item_len, P, mcfg, rn)
+        print(f"  scores: max abs diff {check(name + '.scores', o_s, scores, 2e-5):.3g}, "
+              f"attacked {check(name + '.att_scores', o_as, att_scores, 2e-5):.3g}")
+        arr["out.scores"] = scores
+        arr["out.att_scores"] = att_scores
+        for i, r in enumerate(rn):
+            arr[f"in.noise_eval.{i}"] = r.noise
+    save(name, arr)
+
+
 def main():
     only = set(sys.argv[1:])
 
@@ -296,6 +394,12 @@ def main():
                    train=False)
     if want("model_train"):
         model_case("model_train", B=6, L=50, H=64, h=2, inner=256, n_layers=2, n_items=400, seed=2, train=True)
+
+    if want("bert_gate"):
+        bert_case("bert_gate", B=6, L=50, H=64, h=2, inner=256, n_layers=2, n_items=400, combine="gate", seed=3)
+    if want("bert_fixed_scores"):
+        bert_case("bert_fixed_scores", B=5, L=50, H=64, h=2, inner=256, n_layers=2, n_items=300, combine="fixed",
+                  sigma=0.1, seed=4, mask_ratio=0.3, with_scores=True, use_pos=False)
 
 
 if __name__ == "__main__":

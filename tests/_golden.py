@@ -13,6 +13,7 @@ ENCODER_CASES = [
     "enc_plain", "enc_onelevel", "enc_anneal", "enc_leftpad", "enc_L200_h4", "enc_L200_d64_bidir", "enc_L37_ragged",
 ]
 MODEL_CASES = ["model_eval", "model_eval_stress", "model_train"]
+BERT_CASES = ["bert_gate", "bert_fixed_scores"]
 
 
 class Case:
@@ -45,6 +46,13 @@ class Case:
                            combine_option=str(self.raw["meta.combine"]), rich_calibrated_combine="none", seq_length=50)
         return O.ModelCfg(enc=enc, n_items=n_items, max_seq_length=L,
                           mask_loss_weight=float(self.raw["meta.mask_loss_weight"]))
+
+    def bert_cfg(self):
+        """ModelCfg of an AcBERT4Rec fixture (bert_*.npz)."""
+        cfg = self.model_cfg()
+        cfg.bidirectional = True
+        cfg.use_position_embedding = bool(int(self.raw["meta.use_pos"]))
+        return cfg
 
     def layer_randomness(self, n_layers, train=False):
         out = []
