@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libacattn.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -66,6 +66,15 @@ class LnProblem(C.Structure):
 
 LN_BWD_GRID = 512
 
+
+class EmbedProblem(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("n_table_rows", C.c_int64), ("idx", _f),
+                ("table", _f), ("pos", _f), ("gamma", _f), ("beta", _f), ("eps", C.c_float), ("p_drop", C.c_float),
+                ("keep", _f), ("seed", C.c_uint64), ("seed_device", _f)]
+
+
+EMBED_BWD_CHUNKS = 8
+
 # name -> (restype, argtypes); must list every symbol include/acattn.h declares (tests check this)
 SYMBOLS = {
     "acattn_abi_version": (C.c_int, []),
@@ -78,6 +87,8 @@ SYMBOLS = {
     "acattn_full_sort_ce_bwd": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, _f, _f, C.c_void_p]),
     "acattn_dropout_add_layernorm_fwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, C.c_void_p]),
     "acattn_dropout_add_layernorm_bwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, _f, _f, _f, C.c_void_p]),
+    "acattn_embed_layernorm_fwd": (C.c_int, [C.POINTER(EmbedProblem), _f, _f, C.c_void_p]),
+    "acattn_embed_layernorm_bwd": (C.c_int, [C.POINTER(EmbedProblem), _f, _f, C.c_int64, _f, _f, _f, C.c_void_p]),
     "acattn_sum_rows": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "acattn_linear_wgrad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "acattn_linear_wgrad": (C.c_int, [_f, _f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),

@@ -173,6 +173,33 @@ int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_
   return rc;
 }
 
+static int check_embed(const acattn_embed_problem* p) {
+  if (!p) return fail("embed problem is NULL");
+  if (p->rows < 1 || p->L < 1 || p->rows % p->L != 0) return fail("rows must be a positive multiple of L");
+  if (p->H != 64 && p->H != 128 && p->H != 256) return fail("unsupported hidden size for the fused embedding front end: H must be 64, 128 or 256");
+  if (p->n_table_rows < 1) return fail("n_table_rows must be positive");
+  if (!p->idx || !p->table || !p->gamma || !p->beta) return fail("idx, table, gamma, beta must be non-NULL");
+  if (p->p_drop < 0.f || p->p_drop >= 1.f) return fail("p_drop must lie in [0, 1)");
+  return 0;
+}
+
+int acattn_embed_layernorm_fwd(const acattn_embed_problem* p, float* y, float* stats, void* stream) {
+  if (const int rc = check_embed(p)) return rc;
+  if (!y || !stats) return fail("y and stats must be non-NULL");
+  const int rc = acattn_launch_embed_fwd(*p, y, stats, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_embed_layernorm_bwd(const acattn_embed_problem* p, const float* dy, const float* stats, int64_t padding_idx,
+                               float* d_table, float* d_pos_part, float* dgb_part, void* stream) {
+  if (const int rc = check_embed(p)) return rc;
+  if (!dy || !stats) return fail("dy and stats must be non-NULL");
+  const int rc = acattn_launch_embed_bwd(*p, dy, stats, padding_idx, d_table, d_pos_part, dgb_part, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int64_t acattn_linear_wgrad_workspace_bytes(int64_t M, int32_t K, int32_t N) {
   if (M < 1 || K < 1 || N < 1) return fail("M, K, N must be positive");
   return acattn_linear_wgrad_ws_bytes(M, K, N);

@@ -11,46 +11,12 @@
 #include <algorithm>
 
 #include "acattn_common.h"
+#include "acattn_rowops.h"
 
 namespace {
 
-__device__ __forceinline__ float dpp_row_sum(float v) {  // sum over the 16 lanes of a DPP row
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
-  return v;
-}
-
-// sum over the LPR = H/4 lanes that hold one row (LPR in {16, 32, 64}; lanes of a row are contiguous)
-template <int LPR>
-__device__ __forceinline__ float row_sum(float v) {
-  v = dpp_row_sum(v);
-  if (LPR >= 32) v += __shfl_xor(v, 16);
-  if (LPR >= 64) v += __shfl_xor(v, 32);
-  return v;
-}
-
-// keep-scale (1/(1-p) or 0) for the 4 consecutive columns 4*c4 .. of `row`
 __device__ __forceinline__ f4 ln_keep_scale(const acattn_ln_problem& P, uint64_t seed, int row, int c4, int H) {
-  f4 k = {1.f, 1.f, 1.f, 1.f};
-  if (P.p_drop <= 0.f) return k;
-  const float ks = 1.0f / (1.0f - P.p_drop);
-  if (P.keep) {
-    const uint8_t* kp = P.keep + (size_t)row * H + 4 * c4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) k[e] = kp[e] ? ks : 0.f;
-    return k;
-  }
-  uint32_t x = mix32(((uint32_t)row * (uint32_t)(H / 4) + (uint32_t)c4) ^ (uint32_t)seed) + (uint32_t)(seed >> 32);
-  x = x ? x : 0x6C078965u;
-  const uint32_t w0 = xs32(x), w1 = xs32(x);
-  const uint32_t thr = (uint32_t)(P.p_drop * 65536.0f);
-  k[0] = (w0 & 0xFFFFu) >= thr ? ks : 0.f;
-  k[1] = (w0 >> 16) >= thr ? ks : 0.f;
-  k[2] = (w1 & 0xFFFFu) >= thr ? ks : 0.f;
-  k[3] = (w1 >> 16) >= thr ? ks : 0.f;
-  return k;
+  return row_keep_scale(P.p_drop, P.keep, seed, row, c4, H);
 }
 
 template <int H>

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from .layers import AttackRTransformerEncoder
-from . import ce
+from . import ce, fused_embed
 from .linear import embedding_lookup, full_sort_scores
 from .ops import StructuredMask
 
@@ -32,6 +32,26 @@ def _cfg(config, key, default=None):
     except KeyError:
         val = None
     return default if val is None else val
+
+
+def _front_end(model, item_seq, keep_emb=None):
+    """dropout(LayerNorm(item_embedding(item_seq) + position_embedding)): acsasrec.py:87-95 == acbert4rec.py:163-171.
+    One fused launch each way on the HIP path (fused_embed); hidden sizes it does not cover take the same chain as
+    separate device ops."""
+    pos = model.position_embedding if model.use_position_embedding else None
+    if pos is not None and item_seq.size(1) > pos.num_embeddings:
+        raise IndexError("index out of range in self")  # what nn.Embedding raises on the host
+    if item_seq.is_cuda and fused_embed.supported(model.hidden_size):
+        return fused_embed.embed_layer_norm(item_seq, model.item_embedding, pos, model.LayerNorm, model.dropout.p,
+                                            model.training, keep_emb)
+    input_emb = embedding_lookup(item_seq, model.item_embedding)
+    if pos is not None:
+        position_ids = torch.arange(item_seq.size(1), dtype=torch.long, device=item_seq.device)
+        input_emb = input_emb + pos(position_ids).unsqueeze(0)
+    input_emb = model.LayerNorm(input_emb)
+    if keep_emb is not None:
+        return input_emb * (keep_emb.to(input_emb.dtype) / (1.0 - model.dropout.p))
+    return model.dropout(input_emb)
 
 
 class SequentialRecommender(nn.Module):
@@ -131,16 +151,7 @@ class ACSASRec(SequentialRecommender):
             module.bias.data.zero_()
 
     def forward(self, item_seq, item_seq_len, is_train=False, _rnds=None, _keep_emb=None):
-        item_emb = embedding_lookup(item_seq, self.item_embedding)
-        input_emb = item_emb
-        if self.use_position_embedding:
-            position_ids = torch.arange(item_seq.size(1), dtype=torch.long, device=item_seq.device)
-            input_emb = item_emb + self.position_embedding(position_ids).unsqueeze(0)
-        input_emb = self.LayerNorm(input_emb)
-        if _keep_emb is not None:
-            input_emb = input_emb * (_keep_emb.to(input_emb.dtype) / (1.0 - self.dropout.p))
-        else:
-            input_emb = self.dropout(input_emb)
+        input_emb = _front_end(self, item_seq, _keep_emb)
         mask = self.get_structured_mask(item_seq, self.bidirectional)
         trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
         all_attack_masks = trm_output[1]
@@ -323,18 +334,7 @@ class AcBERT4Rec(SequentialRecommender):
 
     # ---- model ------------------------------------------------------------------------------------------------------
     def forward(self, item_seq, _rnds=None, _keep_emb=None):
-        item_emb = embedding_lookup(item_seq, self.item_embedding)
-        input_emb = item_emb
-        if self.use_position_embedding:
-            if item_seq.size(1) > self.position_embedding.num_embeddings:
-                raise IndexError("index out of range in self")  # what nn.Embedding raises on the host
-            position_ids = torch.arange(item_seq.size(1), dtype=torch.long, device=item_seq.device)
-            input_emb = item_emb + self.position_embedding(position_ids).unsqueeze(0)
-        input_emb = self.LayerNorm(input_emb)
-        if _keep_emb is not None:
-            input_emb = input_emb * (_keep_emb.to(input_emb.dtype) / (1.0 - self.dropout.p))
-        else:
-            input_emb = self.dropout(input_emb)
+        input_emb = _front_end(self, item_seq, _keep_emb)
         mask = self.get_structured_mask(item_seq, bidirectional=True)
         trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
         attacked_output, calibrated_output = trm_output[0][-1]

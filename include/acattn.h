@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 6
+#define ACATTN_ABI_VERSION 7
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -167,6 +167,35 @@ int acattn_dropout_add_layernorm_fwd(const acattn_ln_problem* p, float* y, float
  * (dgamma, dbeta), or NULL; the caller adds the partials (and folds dres when the residual was broadcast). */
 int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy, const float* stats, float* dz,
                                      float* dres, float* dgb_part, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * y = dropout(LayerNorm(item_embedding[idx] + position_embedding[position])): the front end of both models
+ * (recbole/model/sequential_recommender/acsasrec.py:87-95, acbert4rec.py:163-171).  Rows of H in {64, 128, 256}. */
+#define ACATTN_EMBED_BWD_CHUNKS 8 /* the backward runs L x 8 workgroups: leading dimension of its partial buffers */
+typedef struct acattn_embed_problem {
+  int32_t rows, L, H;     /* rows = B*L; row r sits at position r % L */
+  int64_t n_table_rows;   /* rows of `table` (ids outside [0, n) are clamped, never dereferenced out of bounds) */
+  const int64_t* idx;     /* [rows] item ids (item_seq, row-major [B,L]) */
+  const float* table;     /* [n_table_rows,H] item_embedding.weight */
+  const float* pos;       /* [>=L,H] position_embedding.weight, or NULL (use_position_embedding: False) */
+  const float* gamma;     /* [H] LayerNorm.weight */
+  const float* beta;      /* [H] LayerNorm.bias */
+  float eps;              /* layer_norm_eps */
+  float p_drop;           /* hidden_dropout_prob in training, 0 in eval (the dropout FOLLOWS the norm here) */
+  const uint8_t* keep;    /* optional explicit keep mask [rows,H]; NULL = counter RNG from (seed, seed_device) */
+  uint64_t seed;
+  const uint64_t* seed_device;
+} acattn_embed_problem;
+
+/* stats[rows,2] receives (mean, 1/std) per row for the backward. */
+int acattn_embed_layernorm_fwd(const acattn_embed_problem* p, float* y, float* stats, void* stream);
+
+/* d_table [n_table_rows,H] must be ZERO-INITIALISED by the caller: rows are accumulated with float atomics and rows
+ * whose id == padding_idx are skipped (nn.Embedding(padding_idx=0): acsasrec.py:33); pass padding_idx = -1 for none.
+ * d_pos_part [ACATTN_EMBED_BWD_CHUNKS, L, H] (or NULL) and dgb_part [ACATTN_EMBED_BWD_CHUNKS * L, 2, H] (or NULL)
+ * receive partial sums of the position-embedding and (dgamma, dbeta) gradients; the caller adds the partials. */
+int acattn_embed_layernorm_bwd(const acattn_embed_problem* p, const float* dy, const float* stats, int64_t padding_idx,
+                               float* d_table, float* d_pos_part, float* dgb_part, void* stream);
 
 /* out[bt, c] = sum_r x[bt, r, c]  (x is [batch, R, C] contiguous).  The reductions of the training step's backward:
  * bias gradients (sum over B*L rows), split-K slabs, per-(b,head) parameter partials, per-head gate gradients. */

@@ -42,7 +42,9 @@ def test_abi_version(lib):
 
 def test_ctypes_layout_matches_c(tmp_path):
     """Compile a tiny C program against include/acattn.h and compare sizeof/offsetof with ctypes."""
-    fields = {"acattn_problem": _lib.Problem, "acattn_fwd_out": _lib.FwdOut, "acattn_bwd_io": _lib.BwdIO}
+    fields = {"acattn_problem": _lib.Problem, "acattn_fwd_out": _lib.FwdOut, "acattn_bwd_io": _lib.BwdIO,
+              "acattn_ce_problem": _lib.CeProblem, "acattn_ln_problem": _lib.LnProblem,
+              "acattn_embed_problem": _lib.EmbedProblem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "acattn.h"', 'int main(void){']
     for cname, cls in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -1,0 +1,80 @@
+"""GPU suite (-m gpu): the fused embedding front end dropout(LayerNorm(E[idx] + P)) against torch ops in fp64."""
+import pytest
+import torch
+
+from ac_tsr_amd import fused_embed
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _modules(N, L, H, with_pos, g):
+    emb = torch.nn.Embedding(N, H, padding_idx=0)
+    pos = torch.nn.Embedding(L + 3, H) if with_pos else None  # more rows than positions: only the first L are touched
+    norm = torch.nn.LayerNorm(H, eps=1e-12)
+    with torch.no_grad():
+        emb.weight.copy_(torch.randn(N, H, generator=g))
+        if pos is not None:
+            pos.weight.copy_(0.5 * torch.randn(L + 3, H, generator=g))
+        norm.weight.copy_(1 + 0.3 * torch.randn(H, generator=g))
+        norm.bias.copy_(0.3 * torch.randn(H, generator=g))
+    return emb, pos, norm
+
+
+@pytest.mark.parametrize("B,L,H,N", [(512, 50, 64, 100000), (7, 37, 128, 300), (3, 50, 256, 50), (1, 1, 64, 5)])
+@pytest.mark.parametrize("with_pos", [True, False])
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_embed_layernorm_matches_torch(B, L, H, N, with_pos, p):
+    g = torch.Generator().manual_seed(B + L + H)
+    emb, pos, norm = _modules(N, L, H, with_pos, g)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    idx = torch.randint(1, N, (B, L), generator=g) * (torch.arange(L)[None, :] < lens[:, None])
+    keep = torch.empty(B, L, H).bernoulli_(1 - p, generator=g) if p > 0 else None
+    cot = torch.randn(B, L, H, generator=g)
+    # fp64 reference
+    Ed = emb.weight.detach().double().requires_grad_(True)
+    Pd = pos.weight.detach().double().requires_grad_(True) if with_pos else None
+    wd, bd = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    x = Ed[idx] + (Pd[:L].unsqueeze(0) if with_pos else 0)
+    ref = torch.nn.functional.layer_norm(x, (H,), wd, bd, 1e-12)
+    if keep is not None:
+        ref = ref * keep.double() / (1 - p)
+    leaves = [Ed, wd, bd] + ([Pd] if with_pos else [])
+    grads = torch.autograd.grad((ref * cot.double()).sum(), leaves)
+    grads[0][0] = 0  # nn.Embedding(padding_idx=0): the padding row receives no gradient
+    # fused
+    emb_c, norm_c = emb.to(DEV), norm.to(DEV)
+    pos_c = pos.to(DEV) if with_pos else None
+    y = fused_embed.embed_layer_norm(idx.to(DEV), emb_c, pos_c, norm_c, p, training=False,
+                                     keep=None if keep is None else keep.to(DEV))
+    assert (y.detach().cpu() - ref.detach().float()).abs().max() <= 3e-5
+    got = torch.autograd.grad((y * cot.to(DEV)).sum(), [emb_c.weight, norm_c.weight, norm_c.bias] +
+                              ([pos_c.weight] if with_pos else []))
+    for a, b in zip(got, grads):
+        assert (a.cpu() - b.float()).abs().max() <= 1e-4 * b.abs().max() + 1e-6
+    if with_pos:
+        assert got[3][L:].abs().max() == 0
+
+
+def test_counter_dropout_statistics_eval_identity_and_bad_ids():
+    g = torch.Generator().manual_seed(0)
+    B, L, H, N = 256, 50, 64, 1000
+    emb, pos, norm = (m.to(DEV) if m is not None else None for m in _modules(N, L, H, True, g))
+    idx = torch.randint(1, N, (B, L), generator=g).to(DEV)
+    torch.manual_seed(1)
+    a = fused_embed.embed_layer_norm(idx, emb, pos, norm, 0.5, training=True)
+    b = fused_embed.embed_layer_norm(idx, emb, pos, norm, 0.5, training=True)
+    e = fused_embed.embed_layer_norm(idx, emb, pos, norm, 0.5, training=False)
+    zero_a, zero_b = (a == 0).float().mean().item(), (b == 0).float().mean().item()
+    assert abs(zero_a - 0.5) < 0.01 and abs(zero_b - 0.5) < 0.01 and not torch.equal(a == 0, b == 0)
+    kept = a != 0
+    assert (a[kept] - 2 * e[kept]).abs().max() <= 1e-5  # survivors are scaled by 1 / (1 - p)
+    ref = torch.nn.functional.layer_norm(emb(idx) + pos.weight[:L], (H,), norm.weight, norm.bias, 1e-12)
+    assert (e - ref).abs().max() <= 3e-5
+    # ids outside the table are clamped, not dereferenced
+    bad = idx.clone()
+    bad[0, 0], bad[0, 1] = N + 12345, -7
+    out = fused_embed.embed_layer_norm(bad, emb, pos, norm, 0.0, training=False)
+    assert torch.isfinite(out).all()
+    with pytest.raises(IndexError):
+        fused_embed.embed_layer_norm(torch.ones(2, L + 4, dtype=torch.long, device=DEV), emb, pos, norm, 0.0, False)
