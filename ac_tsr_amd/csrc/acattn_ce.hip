@@ -12,6 +12,8 @@
 // d out^T = E^T . dl^T, and d E accumulates in registers over the sweep (no atomics anywhere).  What crosses
 // workgroups is small: (max, sum-exp) pairs per (row, wave) in the forward, one [B, H] slab of d out per
 // workgroup in the backward, each folded by a second tiny kernel.
+#include <algorithm>
+
 #include "acattn_common.h"
 
 namespace {
@@ -153,6 +155,7 @@ template <int CH, int NTILES, bool WITH_TABLE_GRAD>
 __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_problem P, const float* __restrict__ lse,
                                                             const float* __restrict__ coef,
                                                             float* __restrict__ d_out,
+                                                            float* __restrict__ d_out_slab,
                                                             float* __restrict__ d_table) {
   using C = CeCfg<CH, NTILES>;
   constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);  // transpose-scratch row stride: 16 * odd -> conflict-free column reads
@@ -183,19 +186,40 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
     for (int dt = 0; dt < C::DT; ++dt) dE[t][dt] = f4{0.f, 0.f, 0.f, 0.f};
 
   const int nrb = (B + 15) >> 4;
-  for (int rb = 0; rb < nrb; ++rb) {
-    __syncthreads();  // Hs and the exchange area of the previous block are free
-    for (int idx = threadIdx.x; idx < 16 * (CH / 4); idx += blockDim.x) {
+  // The batch rows of block rb+1 (and their lse / coef / target) are fetched into registers while block rb is on the
+  // matrix cores: with one wave per SIMD nothing else would hide that L2 round trip, 32+ times per launch.
+  constexpr int HV = (16 * (CH / 4) + 64 * CE_NW - 1) / (64 * CE_NW);  // float4s of a [16, CH] block per thread
+  f4 h_next[HV];
+  float lse_next = 0.f, cf_next = 0.f;
+  int tgt_next = -1;
+  auto prefetch = [&](int rb) {
+#pragma unroll
+    for (int u = 0; u < HV; ++u) {
+      const int idx = threadIdx.x + u * 64 * CE_NW;
       const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (16 * rb + r < B) v = *(const f4*)(P.out + (size_t)(16 * rb + r) * CH + 4 * c4);
-      *(f4*)(Hs + r * C::ES + 4 * c4) = v;
+      h_next[u] = f4{0.f, 0.f, 0.f, 0.f};
+      if (idx < 16 * (CH / 4) && 16 * rb + r < B) h_next[u] = *(const f4*)(P.out + (size_t)(16 * rb + r) * CH + 4 * c4);
     }
     const int row = 16 * rb + c;
-    const bool row_ok = row < B;
-    const float l2 = row_ok ? lse[row] * kLog2e : 0.f;
-    const float cf = row_ok ? coef[row] : 0.f;
-    const int tgt = row_ok ? (int)P.target[row] - item0 : -1;  // target as an index into this wave's items
+    const bool ok = row < B;
+    lse_next = ok ? lse[row] : 0.f;
+    cf_next = ok ? coef[row] : 0.f;
+    tgt_next = ok ? (int)P.target[row] : -1;
+  };
+  prefetch(0);
+  for (int rb = 0; rb < nrb; ++rb) {
+    __syncthreads();  // Hs and the exchange area of the previous block are free
+#pragma unroll
+    for (int u = 0; u < HV; ++u) {
+      const int idx = threadIdx.x + u * 64 * CE_NW;
+      const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+      if (idx < 16 * (CH / 4)) *(f4*)(Hs + r * C::ES + 4 * c4) = h_next[u];
+    }
+    const bool row_ok = 16 * rb + c < B;
+    const float l2 = lse_next * kLog2e;
+    const float cf = cf_next;
+    const int tgt = row_ok ? tgt_next - item0 : -1;  // target as an index into this wave's items
+    if (rb + 1 < nrb) prefetch(rb + 1);
     __syncthreads();
 
     // logits^T tile set and dl = coef * (softmax - onehot), layout: lane = batch row, registers = items
@@ -271,11 +295,16 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         f4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < CE_NW; ++w) sum += *(const f4*)(X + w * XS + r * C::ES + 4 * c4);
-        // one [16, CH] tile per workgroup and row block: ~50 MB of float atomics per call, spread over all rows and
-        // issued under the MFMA work of the next block (d_out is zeroed by the launcher)
-        float* dst = d_out + (size_t)(16 * rb + r) * CH + 4 * c4;
+        // one [16, CH] tile per workgroup and row block.  Normally it goes to the workgroup's own [B, CH] slab and
+        // ce_bwd_reduce_kernel folds the slabs (plain stores: 7.3 M float atomics per call cost 64 us of 330).
+        // With very many rows (slabs beyond kSlabLimit) it is added to d_out with float atomics instead.
+        const size_t o = (size_t)(16 * rb + r) * CH + 4 * c4;
+        if (d_out_slab) {
+          *(f4*)(d_out_slab + (size_t)blockIdx.x * B * CH + o) = sum;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, sum[e]);
+          for (int e = 0; e < 4; ++e) atomicAdd(d_out + o + e, sum[e]);
+        }
       }
     }
   }
@@ -292,6 +321,37 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
       }
   }
 }
+
+// d_out[i] = sum over workgroups of slab[wg][i]: 32 outputs per workgroup, 8 threads per output (each sums every
+// 8th slab with 8 loads in flight), folded through LDS -- the same shape as wgrad_reduce_kernel.
+__global__ void __launch_bounds__(256) ce_bwd_reduce_kernel(const float* __restrict__ slab, const int n_slabs,
+                                                             const int64_t n_out, float* __restrict__ d_out) {
+  const int sl = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + sl;
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  if (i < n_out) {
+    const float* ps = slab + i;
+    int p = q;
+    for (; p + 56 < n_slabs; p += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += ps[(size_t)(p + 8 * u) * n_out];
+    }
+    for (; p < n_slabs; p += 8) a[0] += ps[(size_t)p * n_out];
+  }
+  __shared__ float red[8][32];
+  red[q][sl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (q == 0 && i < n_out) {
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += red[u][sl];
+    d_out[i] = v;
+  }
+}
+
+constexpr int64_t kSlabLimit = 96ll << 20;  // bytes of d_out slabs above which the backward uses atomics
 
 static int num_cus() {
   static int n = 0;
@@ -327,24 +387,31 @@ int launch_fwd_t(const acattn_ce_problem& p, void* ws, float* lse, float* row_lo
 }
 
 template <int CH, int NTILES>
-int launch_bwd_t(const acattn_ce_problem& p, const float* lse, const float* coef, float* d_out, float* d_table,
+int launch_bwd_t(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out, float* d_table,
                  hipStream_t stream) {
   using C = CeCfg<CH, NTILES>;
   const int n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
   constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);
   constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
   const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
-  const hipError_t e = hipMemsetAsync(d_out, 0, (size_t)p.B * CH * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  const int64_t n_out = (int64_t)p.B * CH;
+  float* slab = (n_wg * n_out * (int64_t)sizeof(float) <= kSlabLimit) ? (float*)ws : nullptr;
+  if (!slab) {
+    const hipError_t e = hipMemsetAsync(d_out, 0, (size_t)n_out * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+  }
   if (d_table) {
     auto k = ce_bwd_kernel<CH, NTILES, true>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, d_table);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table);
   } else {
     auto k = ce_bwd_kernel<CH, NTILES, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, d_table);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table);
   }
+  if (slab)
+    hipLaunchKernelGGL(ce_bwd_reduce_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, stream, slab, n_wg, n_out,
+                       d_out);
   return (int)hipGetLastError();
 }
 
@@ -355,7 +422,10 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
   if (CH <= 64 && tiles == 3) tiles = 4;
   if (tiles > max_tiles<CH>()) tiles = max_tiles<CH>();
   const int64_t n_wg = (p.N + CE_NW * 16 * tiles - 1) / (CE_NW * 16 * tiles);
-  return n_wg * CE_NW * p.B * (int64_t)sizeof(float2);
+  const int64_t fwd = n_wg * CE_NW * p.B * (int64_t)sizeof(float2);
+  // backward: one [B, CH] slab of d_out per workgroup (skipped, in favour of atomics, beyond kSlabLimit)
+  const int64_t bwd = n_wg * p.B * CH * (int64_t)sizeof(float);
+  return std::max(fwd, bwd <= kSlabLimit ? bwd : 0);
 }
 
 template <int CH>
@@ -372,13 +442,12 @@ int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss
 template <int CH>
 int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out, float* d_table,
                hipStream_t stream) {
-  (void)ws;
   switch (pick_tiles<CH>(p.N)) {
-    case 1: return launch_bwd_t<CH, 1>(p, lse, coef, d_out, d_table, stream);
-    case 2: return launch_bwd_t<CH, 2>(p, lse, coef, d_out, d_table, stream);
-    case 3: return launch_bwd_t<CH, (CH <= 64 ? 4 : 3)>(p, lse, coef, d_out, d_table, stream);
-    case 4: return launch_bwd_t<CH, (CH <= 64 ? 4 : 3)>(p, lse, coef, d_out, d_table, stream);
-    default: return launch_bwd_t<CH, max_tiles<CH>()>(p, lse, coef, d_out, d_table, stream);
+    case 1: return launch_bwd_t<CH, 1>(p, lse, coef, ws, d_out, d_table, stream);
+    case 2: return launch_bwd_t<CH, 2>(p, lse, coef, ws, d_out, d_table, stream);
+    case 3: return launch_bwd_t<CH, (CH <= 64 ? 4 : 3)>(p, lse, coef, ws, d_out, d_table, stream);
+    case 4: return launch_bwd_t<CH, (CH <= 64 ? 4 : 3)>(p, lse, coef, ws, d_out, d_table, stream);
+    default: return launch_bwd_t<CH, max_tiles<CH>()>(p, lse, coef, ws, d_out, d_table, stream);
   }
 }
 
