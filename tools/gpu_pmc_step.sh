@@ -1,0 +1,23 @@
+#!/bin/bash
+# PMC passes over a few eager training steps: counters of every acattn kernel (backward, CE, ...).
+set -u
+name=${1:-pmc_step}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+pass() {
+  local tag=$1; shift
+  mkdir -p $R/gpurun_out/$name/$tag
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/$name/$tag -o $tag -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --kernel-iters 5 > $R/gpurun_out/$name/$tag/run.log 2>&1
+  echo "pass $tag rc=$?"
+}
+pass sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES || exit 1
+pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_MFMA || exit 1
+pass fetch FETCH_SIZE || exit 1
+pass write WRITE_SIZE || exit 1
+python3 $R/tools/pmc_to_json.py $R/gpurun_out/$name $R/gpurun_out/$name/pmc.json > /dev/null
+python3 - <<PY
+import json
+d=json.load(open("$R/gpurun_out/$name/pmc.json"))["kernels"]
+for k,e in d.items():
+    print(k, {c: e[c] for c in sorted(e)})
+PY
