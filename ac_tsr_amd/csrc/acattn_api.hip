@@ -94,6 +94,7 @@ int acattn_calibrated_attention_bwd(const acattn_problem* p, const acattn_bwd_io
   if (!io->dq || !io->dk || !io->dv || !io->dqa || !io->dka) return fail("dq, dk, dv, dqa, dka must be non-NULL");
   if (p->combine_option == ACATTN_COMBINE_GATE && !io->dgate_logits) return fail("gate combine needs dgate_logits");
   if (!io->dw_order_part || !io->dw_dist_part || !io->dsmall_part) return fail("parameter partial buffers must be non-NULL");
+  if (io->part_stride != 0 && io->part_stride < 2 * (p->H / p->n_heads)) return fail("part_stride is smaller than a partial row");
   const int rc = acattn_launch_bwd(*p, *io, (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;

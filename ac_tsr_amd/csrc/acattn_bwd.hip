@@ -742,10 +742,11 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
         wd += s_dcd[j] * kv;
       }
     }
-    IO.dw_order_part[bh * 2 * DH + d] = wo;
-    IO.dw_dist_part[bh * 2 * DH + d] = wd;
+    IO.dw_order_part[bh * (IO.part_stride ? IO.part_stride : 2 * DH) + d] = wo;
+    IO.dw_dist_part[bh * (IO.part_stride ? IO.part_stride : 2 * DH) + d] = wd;
   }
-  if (threadIdx.x < 4) IO.dsmall_part[bh * 4 + threadIdx.x] = threadIdx.x < 3 ? s_small[threadIdx.x] : 0.f;
+  if (threadIdx.x < 4)
+    IO.dsmall_part[bh * (IO.part_stride ? IO.part_stride : 4) + threadIdx.x] = threadIdx.x < 3 ? s_small[threadIdx.x] : 0.f;
 }
 
 template <int DH, int NT, bool BIG>

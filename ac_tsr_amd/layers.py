@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import fused_ln, ops
-from .linear import skinny_linear
+from .linear import projections, skinny_linear
 from .ops import AttentionConfig, ExplicitRandomness, StructuredMask
 
 
@@ -166,8 +166,9 @@ class AttackRTransformerLayer(nn.Module):
     def forward(self, hidden_states, attention_mask, return_attention_prob=False, return_all_attention_prob=False,
                 _rnd=None):
         att = self.attack_attention
-        mq, mk, mv, qa, ka = att.project(hidden_states)
-        gate_logits = skinny_linear(mq, self.gate) if self.combine_option == 'gate' else None
+        mq, mk, mv, qa, ka, gate_logits = projections(
+            hidden_states, att.query, att.key, att.value, att.attack_query_transform, att.attack_key_transform,
+            self.gate if self.combine_option == 'gate' else None)
         cfg = self._config()
         core_rnd = None
         if _rnd is not None:

@@ -83,6 +83,73 @@ def skinny_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
     return _SkinnyLinear.apply(x, layer.weight, layer.bias, getattr(layer, "_acattn_attack", False))
 
 
+class _Projections(torch.autograd.Function):
+    """The six projections in front of the attention core as ONE autograd node:
+        mq, mk, mv = query/key/value(x)                     recbole/model/layers.py:687-689
+        qa, ka     = attack_query/key_transform(mq, mk)     layers.py:658-659
+        gate       = gate(mq)                               layers.py:887 (combine_option 'gate')
+    Forward: the same six GEMMs.  Backward: the cotangents that meet at mq, mk and x are accumulated by the GEMMs
+    themselves (beta = 1) instead of by five separate elementwise adds per layer and pass, and the parameter
+    gradients come from acattn_linear_wgrad.  Gradients reach exactly the leaves the six nn.Linear would feed."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg):
+        mq, mk, mv = F.linear(x, wq, bq), F.linear(x, wk, bk), F.linear(x, wv, bv)
+        qa, ka = F.linear(mq, waq, baq), F.linear(mk, wak, bak)
+        gate = F.linear(mq, wg, bg) if wg is not None else None
+        ctx.save_for_backward(x, mq, mk, wq, wk, wv, waq, wak, wg if wg is not None else x.new_empty(0))
+        ctx.has_gate = wg is not None
+        return mq, mk, mv, qa, ka, gate
+
+    @staticmethod
+    def backward(ctx, dmq, dmk, dmv, dqa, dka, dgate):
+        from .ops import linear_wgrad
+        x, mq, mk, wq, wk, wv, waq, wak, wg = ctx.saved_tensors
+        H = x.shape[-1]
+        two = lambda t: None if t is None else t.reshape(-1, t.shape[-1])
+        x2, mq2, mk2 = two(x), two(mq), two(mk)
+        dmq, dmk, dmv, dqa, dka, dgate = (two(t) for t in (dmq, dmk, dmv, dqa, dka, dgate))
+
+        def acc_(total, g, w):  # total += g @ w inside the GEMM (beta = 1, in place: no copy, no add kernel)
+            if g is None:
+                return total
+            return g @ w if total is None else total.addmm_(g, w)
+
+        # dmq / dmk are the attention node's freshly allocated dq / dk (mq and mk have no consumer outside this node
+        # and the core), so accumulating into them in place touches nothing anyone else reads
+        dmq_t = acc_(acc_(dmq, dqa, waq), dgate if ctx.has_gate else None, wg)
+        dmk_t = acc_(dmk, dka, wak)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = acc_(acc_(acc_(None, dmq_t, wq), dmk_t, wk), dmv, wv)
+            dx = dx.view_as(x) if dx is not None else None
+        grads = [None] * 12
+        others = not _ATTACK_PASS_ONLY  # pass 2 keeps only the attack transforms (trainer.py:678-684)
+
+        def params(slot, inp, g, want):
+            if want and g is not None and (ctx.needs_input_grad[slot] or ctx.needs_input_grad[slot + 1]):
+                grads[slot - 1], grads[slot] = linear_wgrad(inp, g, ctx.needs_input_grad[slot + 1])
+
+        params(1, x2, dmq_t, others)
+        params(3, x2, dmk_t, others)
+        params(5, x2, dmv, others)
+        params(7, mq2, dqa, True)
+        params(9, mk2, dka, True)
+        if ctx.has_gate:
+            params(11, mq2, dgate, others)
+        return (dx, *grads)
+
+
+def projections(x, query, key, value, attack_query, attack_key, gate=None):
+    """(mq, mk, mv, qa, ka, gate_logits or None) of one encoder layer; see _Projections."""
+    if not x.is_cuda or not torch.is_grad_enabled():
+        mq, mk, mv = query(x), key(x), value(x)
+        return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None)
+    return _Projections.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
+                              attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
+                              gate.weight if gate is not None else None, gate.bias if gate is not None else None)
+
+
 class _FullSortScores(torch.autograd.Function):
     """scores = output @ E^T over the whole catalogue (acsasrec.py:118-119), with the input gradient
     d_output = d_scores @ E computed as a batched split-K product: its reduction runs over all N items

@@ -240,17 +240,20 @@ class _CalibratedAttention(torch.autograd.Function):
         if cfg.combine_option == "gate":
             dgate_part = torch.empty(B, nh, L, L, device=q.device, dtype=torch.float32)
             io.dgate_logits = _ptr(dgate_part)
-        dwo = torch.empty(B, nh, 2 * dh, device=q.device, dtype=torch.float32)
-        dwd = torch.empty(B, nh, 2 * dh, device=q.device, dtype=torch.float32)
-        dsm = torch.empty(B, nh, 4, device=q.device, dtype=torch.float32)
-        io.dw_order_part, io.dw_dist_part, io.dsmall_part = _ptr(dwo), _ptr(dwd), _ptr(dsm)
+        # the three per-(b, head) partial sums share ONE [B*nh, 4*dh + 4] buffer, reduced in a single pass
+        width = 4 * dh + 4
+        part = torch.empty(B * nh, width, device=q.device, dtype=torch.float32)
+        base = part.data_ptr()
+        io.dw_order_part, io.dw_dist_part, io.dsmall_part = base, base + 4 * 2 * dh, base + 4 * 4 * dh
+        io.part_stride = width
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
         if dgate_part is not None:
             dgate = sum_rows(dgate_part, 1)  # the gate is shared by the heads (layers.py:887 unsqueeze(1))
-        small = sum_rows(dsm.view(-1, 4), 0)
-        g_wo = sum_rows(dwo.view(-1, 2 * dh), 0).view_as(w_order) if w_order is not None else None
+        tot = sum_rows(part, 0)
+        small = tot[4 * dh:]
+        g_wo = tot[:2 * dh].view_as(w_order) if w_order is not None else None
         g_bo = small[0:1].view_as(b_order) if w_order is not None else None
-        g_wd = sum_rows(dwd.view(-1, 2 * dh), 0).view_as(w_dist) if w_dist is not None else None
+        g_wd = tot[2 * dh:4 * dh].view_as(w_dist) if w_dist is not None else None
         g_bd = small[1:2].view_as(b_dist) if w_dist is not None else None
         g_sc = small[2:3].view_as(scalar) if w_dist is not None else None
         g_rr = small[3:4].view_as(rich_ratio) if rich_ratio is not None else None

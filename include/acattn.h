@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 7
+#define ACATTN_ABI_VERSION 8
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -121,6 +121,9 @@ typedef struct acattn_bwd_io {
   float* dw_order_part; /* [B,nh,2*dh] */
   float* dw_dist_part;  /* [B,nh,2*dh] */
   float* dsmall_part;   /* [B,nh,4]: d b_order, d b_dist, d scalar, d rich_ratio */
+  int32_t part_stride;  /* row stride (floats) of the three partial buffers; 0 = dense (2*dh, 2*dh, 4).  With a
+                           common stride the three may be column ranges of ONE [B*nh, stride] buffer, which the
+                           caller then reduces in a single pass */
 } acattn_bwd_io;
 
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
