@@ -282,9 +282,12 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
   auto mask4 = [&](int t) -> f4 {
     const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
     if (causal && (16 * t + 15 > i0)) {
+      // key 16t+4g+r lies after query i0+c  <=>  (c - 4g) + 16 (qb - t) < r : one lane constant and compares
+      // against the literals 0..3 (comparing two per-element index registers made the compiler keep -- and spill -- them)
+      const int dq = (c - 4 * g) + 16 * (qb - t);
       f4 m;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) m[r] = (16 * t + 4 * g + r > i) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
+      for (int r = 0; r < 4; ++r) m[r] = (dq < r) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
       return m;
     }
     return km4;
