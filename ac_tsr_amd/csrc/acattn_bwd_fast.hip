@@ -201,9 +201,10 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   auto mask4 = [&](int t) -> f4 {
     const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
     if (causal && (16 * t + 15 > i0)) {
+      const int dq = (c - 4 * g) + 16 * (qb - t);  // key after query  <=>  dq < r  (see acattn_fwd_dma.hip)
       f4 m;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) m[r] = (16 * t + 4 * g + r > i) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
+      for (int r = 0; r < 4; ++r) m[r] = (dq < r) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
       return m;
     }
     return km4;

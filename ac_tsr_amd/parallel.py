@@ -48,46 +48,78 @@ class GradSynchronizer:
     `bucket_bytes` splits the flat buffer into a few large collectives so the first ones can start
     while later ones are still queued; the default keeps the (dominant) embedding gradient in buckets of
     32 MiB, far above the latency-bound regime of an xGMI ring step.
+
+    Two ways to fill the buffer:
+      * accumulate_in_place=False (default): `.grad` starts as None every step, autograd STORES each first gradient
+        (no zero-fill of 27 MB, no read-modify-write per parameter) and `pack()` gathers them into the flat buffer
+        with one multi-tensor copy; afterwards `.grad` of every parameter is a view of the (reduced) flat buffer,
+        which is what the optimizer reads.  Inside a captured graph the trainer records `pack()` with the step.
+      * accumulate_in_place=True: `.grad` are permanent views of the flat buffer and autograd accumulates into
+        them (one small add kernel per parameter and step; supports gradient accumulation over micro-batches).
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None,
+                 accumulate_in_place: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params]
         assert self.params, "no parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
+        self.views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)  # autograd accumulates in place into this view
+            self.views.append(self.flat[off:off + n].view_as(p))
             off += n
+        self.in_place = accumulate_in_place
+        if self.in_place:
+            self.attach()
         per = max(1, bucket_bytes // self.flat.element_size())
         self.buckets = [self.flat[s:min(s + per, total)] for s in range(0, total, per)]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
+
+    def attach(self) -> None:
+        """Make every parameter's .grad the corresponding view of the flat buffer."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def zero_grad(self) -> None:
-        self.flat.zero_()
-        for p in self.params:  # re-attach views if something replaced .grad (e.g. set_to_none)
-            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
-                self._reattach()
-                break
+        if self.in_place:
+            self.flat.zero_()
+            if any(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(self.params, self.views)):
+                self.attach()  # something replaced .grad (e.g. set_to_none)
+        else:
+            for p in self.params:
+                p.grad = None
 
-    def _reattach(self) -> None:
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+    def pack(self) -> None:
+        """Gather the parameters' gradients into the flat buffer (no-op for gradients that already live there)."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                src.append(g)
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def all_reduce(self) -> None:
+        """After this call every parameter's .grad is a view of the flat buffer holding the rank-averaged gradient."""
+        if not self.in_place:
+            self.pack()
+            self.attach()
         if self.world <= 1:
             return
-        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        works = [dist.all_reduce(b, op=op, group=self.group, async_op=True) for b in self.buckets]
         for w in works:
             w.wait()
-        self.flat.div_(self.world)
+        if not self._avg:
+            self.flat.div_(self.world)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:

@@ -93,6 +93,8 @@ class AttackSASRecTrainer:
             if self.grad_sync is not None:
                 self.grad_sync.all_reduce()
             self.optimizer.step()
+        elif self.grad_sync is not None:
+            self.grad_sync.pack()  # captured with the step; the collective and the optimizer stay outside the graph
         return attacked_loss, calibrated_loss
 
     _seed_t = None
@@ -119,6 +121,8 @@ class AttackSASRecTrainer:
         with torch.cuda.graph(graph):
             outs = self._eager_step(self._static_in, with_optimizer=self._graph_has_optimizer)
         self._graph, self._static_out = graph, outs
+        if self.grad_sync is not None:
+            self.grad_sync.attach()  # from now on .grad are the flat views the captured pack() fills on every replay
         return self
 
     def train_step(self, interaction, check_nan: bool = False):

@@ -88,9 +88,32 @@ def test_shard_batch_covers_everything():
             assert seen == list(range(n))
 
 
+def test_pack_mode_stores_gradients_and_hands_the_optimizer_flat_views():
+    model = _model()
+    sync = parallel.GradSynchronizer(model.parameters())  # default: accumulate_in_place=False
+    x, y = _batch()
+    ref = _model()
+    ref.load_state_dict(model.state_dict())
+    torch.nn.functional.cross_entropy(ref(x), y).backward()
+    for _ in range(2):  # twice: a stale flat buffer must not leak into the next step
+        sync.zero_grad()
+        assert all(p.grad is None for p in model.parameters())
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        sync.all_reduce()
+        lo, hi = sync.flat.data_ptr(), sync.flat.data_ptr() + sync.flat.numel() * 4
+        for p, q in zip(model.parameters(), ref.parameters()):
+            assert lo <= p.grad.data_ptr() < hi and torch.equal(p.grad, q.grad)
+    # a parameter that received no gradient reads as zeros
+    sync.zero_grad()
+    first = next(model.parameters())
+    sync.flat.fill_(7.0)
+    sync.all_reduce()
+    assert first.grad.abs().sum() == 0
+
+
 def test_grad_views_survive_zero_grad_and_accumulate_in_place():
     model = _model()
-    sync = parallel.GradSynchronizer(model.parameters())
+    sync = parallel.GradSynchronizer(model.parameters(), accumulate_in_place=True)
     x, y = _batch()
     sync.zero_grad()
     torch.nn.functional.cross_entropy(model(x), y).backward()
