@@ -32,8 +32,7 @@ constexpr float kLn2 = 0.69314718055994530942f;
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int DH, bool ADV>
-__global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_problem P, const acattn_fwd_out O,
-                                                                 const int stagger) {
+__global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_problem P, const acattn_fwd_out O) {
   constexpr int KS = DH / 4;
   constexpr int DT = DH / 16;
   constexpr int VS = DH + 4;
@@ -50,16 +49,6 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   const size_t rowbase = (size_t)b * L;
   const int hoff = h * DH;
   const size_t bh = (size_t)b * nh + h;
-
-  // Workgroups that share a CU would otherwise run in lockstep (all load, then all compute, then all
-  // store) and leave HBM idle while computing.  The k-th workgroup dealt to a CU (dispatch is round-robin,
-  // so k ~ blockIdx / #CUs; a speed heuristic only) starts k * stagger sleep quanta later, so that its loads
-  // overlap its neighbours' arithmetic.
-  if (stagger > 0) {
-    // HW_REG_HW_ID[3:0] = wave slot inside the SIMD: the k-th workgroup resident on a CU sits in slot ~k
-    const int gen = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3;
-    for (int k = 0; k < gen * stagger; ++k) __builtin_amdgcn_s_sleep(32);
-  }
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;             // [LP][VS]
@@ -254,19 +243,16 @@ template <int DH>
 int launch_fast(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
   const int nT = (p.L + 15) / 16, LP = nT * 16;
   const int GS = (p.L + 3) & ~3;
-  size_t lds = (size_t)((p.adversarial ? 3 : 2) * LP * (DH + 4) + 4 * LP + (p.adversarial ? p.L * GS : 0)) * sizeof(float);
+  const size_t lds = (size_t)((p.adversarial ? 3 : 2) * LP * (DH + 4) + 4 * LP + (p.adversarial ? p.L * GS : 0)) * sizeof(float);
   const dim3 grid(p.B * p.n_heads), block(64 * nT);
-  static const size_t extra = getenv("ACATTN_EXTRA_LDS") ? (size_t)atoi(getenv("ACATTN_EXTRA_LDS")) : 0;  // residency experiments
-  static const int stagger = getenv("ACATTN_STAGGER") ? atoi(getenv("ACATTN_STAGGER")) : 0;
-  lds += extra;
   if (lds > 64 * 1024) {
-    hipFuncSetAttribute((const void*)acattn_fwd_fast_kernel<DH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)acattn_fwd_fast_kernel<DH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)acattn_fwd_fast_kernel<DH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)acattn_fwd_fast_kernel<DH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   if (p.adversarial)
-    hipLaunchKernelGGL((acattn_fwd_fast_kernel<DH, true>), grid, block, lds, stream, p, o, stagger);
+    hipLaunchKernelGGL((acattn_fwd_fast_kernel<DH, true>), grid, block, lds, stream, p, o);
   else
-    hipLaunchKernelGGL((acattn_fwd_fast_kernel<DH, false>), grid, block, lds, stream, p, o, stagger);
+    hipLaunchKernelGGL((acattn_fwd_fast_kernel<DH, false>), grid, block, lds, stream, p, o);
   return (int)hipGetLastError();
 }
 
