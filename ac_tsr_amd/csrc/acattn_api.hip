@@ -1,4 +1,5 @@
 // C-ABI entry points of libacattn.so (include/acattn.h): argument validation, dispatch, error text.
+#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -197,6 +198,24 @@ int acattn_embed_layernorm_bwd(const acattn_embed_problem* p, const float* dy, c
   if (const int rc = check_embed(p)) return rc;
   if (!dy || !stats) return fail("dy and stats must be non-NULL");
   const int rc = acattn_launch_embed_bwd(*p, dy, stats, padding_idx, d_table, d_pos_part, dgb_part, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_mask_penalty_fwd(const float* m, int64_t n, float* workspace, float* norm, void* stream) {
+  if (!m || !workspace || !norm) return fail("m, workspace and norm must be non-NULL");
+  if (n < 1) return fail("n must be positive");
+  if (((uintptr_t)m & 15) != 0) return fail("m must be 16-byte aligned");
+  const int rc = acattn_launch_penalty_fwd(m, n, workspace, norm, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_mask_penalty_bwd(const float* m, const float* norm, const float* d_norm, int64_t n, float* d_m, void* stream) {
+  if (!m || !norm || !d_norm || !d_m) return fail("m, norm, d_norm and d_m must be non-NULL");
+  if (n < 1) return fail("n must be positive");
+  if ((((uintptr_t)m | (uintptr_t)d_m) & 15) != 0) return fail("m and d_m must be 16-byte aligned");
+  const int rc = acattn_launch_penalty_bwd(m, norm, d_norm, n, d_m, (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;
 }

@@ -153,3 +153,6 @@ int acattn_launch_linear_wgrad(const float* x, const float* dy, int64_t M, int K
 int acattn_launch_embed_fwd(const acattn_embed_problem& p, float* y, float* stats, hipStream_t stream);
 int acattn_launch_embed_bwd(const acattn_embed_problem& p, const float* dy, const float* stats, int64_t padding_idx,
                             float* d_table, float* d_pos_part, float* dgb_part, hipStream_t stream);
+int acattn_launch_penalty_fwd(const float* m, int64_t n, float* ws, float* norm, hipStream_t stream);
+int acattn_launch_penalty_bwd(const float* m, const float* norm, const float* d_norm, int64_t n, float* d_m,
+                              hipStream_t stream);

@@ -17,7 +17,7 @@ from torch import nn
 from .layers import AttackRTransformerEncoder
 from . import ce, fused_embed
 from .linear import embedding_lookup, full_sort_scores
-from .ops import StructuredMask
+from .ops import StructuredMask, mask_penalty
 
 
 class ModelType(Enum):
@@ -32,6 +32,13 @@ def _cfg(config, key, default=None):
     except KeyError:
         val = None
     return default if val is None else val
+
+
+def _penalty(attack_mask):
+    """torch.norm(1 - attack_mask, p=2) (acsasrec.py:135, acbert4rec.py:231)."""
+    if attack_mask.is_cuda and attack_mask.dtype == torch.float32:
+        return mask_penalty(attack_mask)
+    return torch.norm(1 - attack_mask, p=2)
 
 
 def _front_end(model, item_seq, keep_emb=None):
@@ -181,7 +188,7 @@ class ACSASRec(SequentialRecommender):
         final_attacked_loss = None
         if attacked_output is not None:
             attacked_loss = -self._cal_loss(attacked_output, interaction, attack_loss=True)
-            mask_penalty = [torch.norm(1 - m, p=2) for m in all_attack_masks if m is not None]
+            mask_penalty = [_penalty(m) for m in all_attack_masks if m is not None]
             assert len(mask_penalty) > 0
             mask_penalty = torch.mean(torch.stack(mask_penalty, dim=0))
             if self.trainable_mask_loss_weight:
@@ -371,7 +378,7 @@ class AcBERT4Rec(SequentialRecommender):
         if self.loss_type == 'BPR':
             raise NotImplementedError("the reference computes only the CE loss here (acbert4rec.py:201-209)")
         attacked_loss = -self._cal_loss(attacked_seq_output, pos_items, targets)
-        mask_penalty = torch.mean(torch.stack([torch.norm(1 - m, p=2) for m in all_attack_masks], dim=0))
+        mask_penalty = torch.mean(torch.stack([_penalty(m) for m in all_attack_masks], dim=0))
         if self.trainable_mask_loss_weight:
             final_attacked_loss = attacked_loss + mask_penalty * self.mask_loss_weight[0]
         else:

@@ -345,3 +345,28 @@ def linear_wgrad(x2: torch.Tensor, g2: torch.Tensor, want_bias: bool):
     _lib.check(lib.acattn_linear_wgrad(_ptr(x2), _ptr(g2), M, K, N, _ptr(ws), _ptr(dw), _ptr(db) if want_bias else None,
                                        _stream()), "linear_wgrad")
     return dw, db
+
+
+class _MaskPenalty(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m):
+        _need_cuda("attack mask", m)
+        m = m.contiguous()
+        ws = torch.empty(_lib.PENALTY_WS_FLOATS, device=m.device, dtype=torch.float32)
+        norm = torch.empty((), device=m.device, dtype=torch.float32)
+        _lib.check(_lib.load().acattn_mask_penalty_fwd(_ptr(m), m.numel(), _ptr(ws), _ptr(norm), _stream()), "mask_penalty_fwd")
+        ctx.save_for_backward(m, norm)
+        return norm
+
+    @staticmethod
+    def backward(ctx, d_norm):
+        m, norm = ctx.saved_tensors
+        d_m = torch.empty_like(m)
+        _lib.check(_lib.load().acattn_mask_penalty_bwd(_ptr(m), _ptr(norm), _ptr(d_norm.contiguous()), m.numel(), _ptr(d_m),
+                                                       _stream()), "mask_penalty_bwd")
+        return d_m
+
+
+def mask_penalty(attack_mask: torch.Tensor) -> torch.Tensor:
+    """torch.norm(1 - attack_mask, p=2) (acsasrec.py:131-137) as one pass over the mask each way."""
+    return _MaskPenalty.apply(attack_mask)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 8
+#define ACATTN_ABI_VERSION 9
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -203,6 +203,14 @@ int acattn_embed_layernorm_bwd(const acattn_embed_problem* p, const float* dy, c
 /* out[bt, c] = sum_r x[bt, r, c]  (x is [batch, R, C] contiguous).  The reductions of the training step's backward:
  * bias gradients (sum over B*L rows), split-K slabs, per-(b,head) parameter partials, per-head gate gradients. */
 int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_t C, void* stream);
+
+/* The mask penalty || 1 - M ||_2 over a whole attack-mask tensor (torch.norm(1 - attack_mask, p=2):
+ * recbole/model/sequential_recommender/acsasrec.py:131-137, acbert4rec.py:229-232) and its gradient
+ * d_m = d_norm * (m - 1) / norm.  m has n floats (16-byte aligned); `workspace` holds
+ * ACATTN_PENALTY_WS_FLOATS floats; norm, d_norm are device scalars. */
+#define ACATTN_PENALTY_WS_FLOATS 1024
+int acattn_mask_penalty_fwd(const float* m, int64_t n, float* workspace, float* norm, void* stream);
+int acattn_mask_penalty_bwd(const float* m, const float* norm, const float* d_norm, int64_t n, float* d_m, void* stream);
 
 /* Parameter gradients of y = x W^T + b (torch.nn.functional.linear as called for query/key/value, the attack
  * transforms, dense, the gate and the feed-forward pair: recbole/model/layers.py:687-690, 660-661, 681, 792-794, 863):

@@ -68,3 +68,23 @@ def test_sum_rows_kernel(shape, dim):
     want = x.double().sum(dim)
     assert got.shape == want.shape
     assert (got.double() - want).abs().max() <= 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(512, 2, 50, 50), (3, 4, 37, 37), (1, 1, 1, 3), (2, 2, 50, 51)])
+def test_mask_penalty_matches_torch_norm(shape):
+    """ops.mask_penalty == torch.norm(1 - M, p=2) (acsasrec.py:135) and so does its gradient."""
+    from ac_tsr_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    m = torch.rand(*shape, generator=g)
+    md = m.double().requires_grad_(True)
+    ref = torch.norm(1 - md, p=2)
+    (gref,) = torch.autograd.grad(ref * 0.37, [md])
+    mc = m.to(DEV).requires_grad_(True)
+    out = ops.mask_penalty(mc)
+    assert abs(out.item() - ref.item()) <= 2e-6 * ref.item() + 1e-6
+    (gm,) = torch.autograd.grad(out * 0.37, [mc])
+    assert (gm.cpu().double() - gref).abs().max() <= 1e-6 * gref.abs().max() + 1e-9
+    ones = torch.ones(*shape, device=DEV, requires_grad=True)  # zero norm: zero gradient, like torch
+    o = ops.mask_penalty(ones)
+    (g1,) = torch.autograd.grad(o, [ones])
+    assert o.item() == 0 and g1.abs().max() == 0
