@@ -222,17 +222,30 @@ int acattn_mask_penalty_bwd(const float* m, const float* norm, const float* d_no
 
 int64_t acattn_linear_wgrad_workspace_bytes(int64_t M, int32_t K, int32_t N) {
   if (M < 1 || K < 1 || N < 1) return fail("M, K, N must be positive");
-  return acattn_linear_wgrad_ws_bytes(M, K, N);
+  return acattn_linear_wgrad_ws_bytes(M, K, N, 1);
+}
+
+int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, const int32_t* N, float* const* dw,
+                                float* const* db, int32_t n_items, int64_t M, int32_t K, void* workspace, void* stream) {
+  if (!x || !dy || !N || !dw || !db || !workspace) return fail("x, dy, N, dw, db and workspace must be non-NULL");
+  if (n_items < 1 || n_items > ACATTN_WGRAD_MAX_GROUP) return fail("n_items must lie in [1, ACATTN_WGRAD_MAX_GROUP]");
+  if (M < 1 || K < 1) return fail("M, K must be positive");
+  int n_max = 0;
+  for (int i = 0; i < n_items; ++i) {
+    if (!x[i] || !dy[i] || !dw[i]) return fail("every item needs x, dy and dw");
+    if (N[i] < 1) return fail("N must be positive");
+    if ((N[i] + 63) / 64 != (N[0] + 63) / 64) return fail("grouped items must agree in ceil(N / 64)");
+    n_max = std::max(n_max, (int)N[i]);
+  }
+  if (M * (int64_t)std::max((int)K, n_max) >= (1LL << 40)) return fail("matrix too large");
+  const int rc = acattn_launch_linear_wgrad(x, dy, (const int*)N, dw, db, n_items, M, K, workspace, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
 }
 
 int acattn_linear_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, void* workspace, float* dw,
                         float* db, void* stream) {
-  if (!x || !dy || !dw || !workspace) return fail("x, dy, dw and workspace must be non-NULL");
-  if (M < 1 || K < 1 || N < 1) return fail("M, K, N must be positive");
-  if (M * (int64_t)std::max(K, N) >= (1LL << 40)) return fail("matrix too large");
-  const int rc = acattn_launch_linear_wgrad(x, dy, M, K, N, workspace, dw, db, (hipStream_t)stream);
-  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
-  return rc;
+  return acattn_linear_wgrad_grouped(&x, &dy, &N, &dw, &db, 1, M, K, workspace, stream);
 }
 
 }  // extern "C"

@@ -25,6 +25,16 @@ namespace {
 
 constexpr int kRegs = 64;  // accumulator registers per lane: 16 MFMA tiles x 4
 
+// Up to ACATTN_WGRAD_MAX_GROUP problems of one launch: same M, K and number of 64-wide N blocks, own operands.
+// blockIdx.z selects the item; its partials live in its own slice of the workspace.
+struct WgradGroup {
+  const float* x[ACATTN_WGRAD_MAX_GROUP];
+  const float* dy[ACATTN_WGRAD_MAX_GROUP];
+  float* dw[ACATTN_WGRAD_MAX_GROUP];
+  float* db[ACATTN_WGRAD_MAX_GROUP];
+  int N[ACATTN_WGRAD_MAX_GROUP];
+};
+
 __device__ __forceinline__ f4 load_rows4(const float* base, int64_t row, int64_t M, int ld, int col, int ncols) {
   // 4 consecutive columns of `row`, zero outside the matrix; rows of a matrix with ld % 4 != 0 are only
   // dword-aligned, and its last columns must not be read past the row end
@@ -43,9 +53,15 @@ __device__ __forceinline__ f4 load_rows4(const float* base, int64_t row, int64_t
 }
 
 template <int UNROLL>
-__global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             const int64_t M, const int K, const int N, const int KB,
-                                                             float* __restrict__ part_w, float* __restrict__ part_b) {
+__global__ void __launch_bounds__(256) wgrad_partial_kernel(const WgradGroup G, const int64_t M, const int K,
+                                                             const int KB, const int NB, float* __restrict__ part_w_all,
+                                                             float* __restrict__ part_b_all) {
+  const int it = blockIdx.z;
+  const float* __restrict__ x = G.x[it];
+  const float* __restrict__ dy = G.dy[it];
+  const int N = G.N[it];
+  float* part_w = part_w_all + (size_t)it * KB * NB * gridDim.x * (kRegs * 64);
+  float* part_b = G.db[it] ? part_b_all + (size_t)it * NB * gridDim.x * 64 : nullptr;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int blk = blockIdx.y, nb = blk / KB, kb = blk - nb * KB;
@@ -106,10 +122,15 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const float* __restr
 
 // dW[n, k] for n = nb*64 + 16g + 4r + a, k = kb*64 + 4c + b lives at slot ((a*4 + b)*4 + r) * 64 + 16g + c of
 // every partial (D register r of lane 16g+c is D[4g + r][c]; tile (a, b) holds n-columns {4i + a}, k-columns {4j + b}).
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part_w,
-                                                            const float* __restrict__ part_b, const int P, const int K,
-                                                            const int N, const int KB, float* __restrict__ dw,
-                                                            float* __restrict__ db) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradGroup G, const float* __restrict__ part_w_all,
+                                                            const float* __restrict__ part_b_all, const int P, const int K,
+                                                            const int KB, const int NB) {
+  const int it = blockIdx.z;
+  const int N = G.N[it];
+  float* __restrict__ dw = G.dw[it];
+  float* __restrict__ db = G.db[it];
+  const float* part_w = part_w_all + (size_t)it * KB * NB * P * (kRegs * 64);
+  const float* part_b = part_b_all + (size_t)it * NB * P * 64;
   const int blk = blockIdx.y, nb = blk / KB, kb = blk - nb * KB;
   // 32 slots per workgroup, 8 threads per slot; a thread sums every 8th partial with 8 loads in flight at a time
   // (the kernel is a latency chain otherwise: 4 MB spread over few workgroups), folded through LDS
@@ -165,31 +186,41 @@ int pick_partials(int64_t M, int blocks) {
 
 }  // namespace
 
-int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N) {
+int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N, int n_items) {
   const int KB = (K + 63) / 64, NB = (N + 63) / 64;
   const int P = pick_partials(M, KB * NB);
-  return ((int64_t)KB * NB * P * kRegs * 64 + (int64_t)NB * P * 64) * (int64_t)sizeof(float);
+  return (int64_t)n_items * ((int64_t)KB * NB * P * kRegs * 64 + (int64_t)NB * P * 64) * (int64_t)sizeof(float);
 }
 
-int acattn_launch_linear_wgrad(const float* x, const float* dy, int64_t M, int K, int N, void* ws, float* dw, float* db,
-                               hipStream_t stream) {
-  const int KB = (K + 63) / 64, NB = (N + 63) / 64;
+// n_items problems sharing M, K and NB = ceil(N / 64) (N itself may differ: 50 and 64 both have NB = 1)
+int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, const int* N, float* const* dw,
+                               float* const* db, int n_items, int64_t M, int K, void* ws, hipStream_t stream) {
+  WgradGroup G{};
+  int n_max = 0;
+  for (int i = 0; i < n_items; ++i) {
+    G.x[i] = x[i];
+    G.dy[i] = dy[i];
+    G.dw[i] = dw[i];
+    G.db[i] = db[i];
+    G.N[i] = N[i];
+    n_max = std::max(n_max, N[i]);
+  }
+  const int KB = (K + 63) / 64, NB = (n_max + 63) / 64;
   const int P = pick_partials(M, KB * NB);
   float* part_w = (float*)ws;
-  float* part_b = part_w + (size_t)KB * NB * P * kRegs * 64;
+  float* part_b = part_w + (size_t)n_items * KB * NB * P * kRegs * 64;
   // a wave's loads are all issued before its first MFMA when they fit (one HBM latency instead of several)
   const int64_t groups_per_wave = ((M + 3) / 4 + (int64_t)P * 4 - 1) / ((int64_t)P * 4);
-  const dim3 grid(P, KB * NB);
-  float* pb = db ? part_b : nullptr;
+  const dim3 grid(P, KB * NB, n_items);
   if (groups_per_wave > 4)
-    hipLaunchKernelGGL((wgrad_partial_kernel<7>), grid, dim3(256), 0, stream, x, dy, M, K, N, KB, part_w, pb);
+    hipLaunchKernelGGL((wgrad_partial_kernel<7>), grid, dim3(256), 0, stream, G, M, K, KB, NB, part_w, part_b);
   else if (groups_per_wave >= 4)
-    hipLaunchKernelGGL((wgrad_partial_kernel<4>), grid, dim3(256), 0, stream, x, dy, M, K, N, KB, part_w, pb);
+    hipLaunchKernelGGL((wgrad_partial_kernel<4>), grid, dim3(256), 0, stream, G, M, K, KB, NB, part_w, part_b);
   else
-    hipLaunchKernelGGL((wgrad_partial_kernel<1>), grid, dim3(256), 0, stream, x, dy, M, K, N, KB, part_w, pb);
+    hipLaunchKernelGGL((wgrad_partial_kernel<1>), grid, dim3(256), 0, stream, G, M, K, KB, NB, part_w, part_b);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kRegs * 2, KB * NB), dim3(256), 0, stream, part_w, part_b, P, K, N,
-                     KB, dw, db);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kRegs * 2, KB * NB, n_items), dim3(256), 0, stream, G, part_w, part_b, P,
+                     K, KB, NB);
   return (int)hipGetLastError();
 }

@@ -125,10 +125,11 @@ class _Projections(torch.autograd.Function):
             dx = dx.view_as(x) if dx is not None else None
         grads = [None] * 12
         others = not _ATTACK_PASS_ONLY  # pass 2 keeps only the attack transforms (trainer.py:678-684)
+        jobs = []  # (slot of the weight gradient, input, cotangent, want bias): one grouped launch pair for all of them
 
         def params(slot, inp, g, want):
             if want and g is not None and (ctx.needs_input_grad[slot] or ctx.needs_input_grad[slot + 1]):
-                grads[slot - 1], grads[slot] = linear_wgrad(inp, g, ctx.needs_input_grad[slot + 1])
+                jobs.append((slot, inp, g, ctx.needs_input_grad[slot + 1]))
 
         params(1, x2, dmq_t, others)
         params(3, x2, dmk_t, others)
@@ -137,6 +138,10 @@ class _Projections(torch.autograd.Function):
         params(9, mk2, dka, True)
         if ctx.has_gate:
             params(11, mq2, dgate, others)
+        if jobs:
+            from .ops import linear_wgrad_grouped
+            for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs])):
+                grads[slot - 1], grads[slot] = gw, gb
         return (dx, *grads)
 
 

@@ -52,3 +52,20 @@ def test_skinny_linear_autograd_matches_torch(shape, N):
     assert torch.equal(ya, yb)
     for got, want in zip(ga, gb):
         assert (got - want).abs().max() <= 2e-5 * want.abs().max() + 1e-6
+
+
+def test_grouped_wgrad_equals_individual_calls():
+    """Six projections' worth of weight/bias gradients in one launch pair (mixed N, mixed bias flags, two N-block
+    classes that must be split into separate launches)."""
+    g = torch.Generator().manual_seed(9)
+    M = 25600
+    x, y = torch.randn(M, 64, generator=g).to(DEV), torch.randn(M, 64, generator=g).to(DEV)
+    items = [(x, torch.randn(M, 64, generator=g).to(DEV), True), (x, torch.randn(M, 64, generator=g).to(DEV), False),
+             (y, torch.randn(M, 50, generator=g).to(DEV), True), (x, torch.randn(M, 256, generator=g).to(DEV), True),
+             (y, torch.randn(M, 64, generator=g).to(DEV), True), (y, torch.randn(M, 200, generator=g).to(DEV), False)]
+    got = ops.linear_wgrad_grouped(items)
+    assert len(got) == len(items)
+    for (xi, gi, wb), (dw, db) in zip(items, got):
+        rw, rb = ops.linear_wgrad(xi, gi, wb)
+        assert torch.equal(dw, rw)
+        assert (db is None) == (not wb) and (db is None or torch.equal(db, rb))
