@@ -164,7 +164,9 @@ class AttackRTransformerLayer(nn.Module):
                                adversarial=True, anneal_rate=rate)
 
     def forward(self, hidden_states, attention_mask, return_attention_prob=False, return_all_attention_prob=False,
-                _rnd=None):
+                _rnd=None, _need_attacked=True):
+        """`_need_attacked=False` (set by the encoder for layers whose attacked output nobody can observe) skips the
+        dense / LayerNorm / feed-forward tail of the attacked branch and returns None in its place."""
         att = self.attack_attention
         mq, mk, mv, qa, ka, gate_logits = projections(
             hidden_states, att.query, att.key, att.value, att.attack_query_transform, att.attack_key_transform,
@@ -181,9 +183,11 @@ class AttackRTransformerLayer(nn.Module):
             mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
             seed_tensor=ops.graph_seed_tensor() if core_rnd is None else None,
             rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
-        attacked_attention_output = att.output(ctx_att, hidden_states, getattr(_rnd, "keep_out_att", None))
+        attacked_feedforward_output = None
+        if _need_attacked:
+            attacked_attention_output = att.output(ctx_att, hidden_states, getattr(_rnd, "keep_out_att", None))
+            attacked_feedforward_output = self.feed_forward(attacked_attention_output, getattr(_rnd, "keep_ffn_att", None))
         calibrated_attention_output = att.output(ctx_cal, hidden_states, getattr(_rnd, "keep_out_cal", None))
-        attacked_feedforward_output = self.feed_forward(attacked_attention_output, getattr(_rnd, "keep_ffn_att", None))
         calibrated_feedforward_output = self.feed_forward(calibrated_attention_output, getattr(_rnd, "keep_ffn_cal", None))
         combined_attention_prob = probs.get("calibrated_attention")
         if return_all_attention_prob:
@@ -224,8 +228,11 @@ class AttackRTransformerEncoder(nn.Module):
         all_probs = [] if return_all_attention_prob else None
         for layer_idx, layer_module in enumerate(self.layer):
             rnd = _rnds[layer_idx] if _rnds is not None else None
+            # only the calibrated output feeds the next layer (layers.py:1112): with output_all_encoded_layers=False the
+            # attacked tail (dense, LayerNorm, feed-forward) of every layer but the last is unobservable and skipped
+            need_attacked = output_all_encoded_layers or layer_idx == len(self.layer) - 1
             outs = layer_module(hidden_states, attention_mask, return_attention_prob, return_all_attention_prob,
-                                _rnd=rnd)
+                                _rnd=rnd, _need_attacked=need_attacked)
             attacked_hidden_states, calibrated_hidden_states, attack_mask, combined_attention_prob = outs[:4]
             hidden_states = calibrated_hidden_states  # layers.py:1112
             all_attack_masks.append(attack_mask)

@@ -160,7 +160,7 @@ class ACSASRec(SequentialRecommender):
     def forward(self, item_seq, item_seq_len, is_train=False, _rnds=None, _keep_emb=None):
         input_emb = _front_end(self, item_seq, _keep_emb)
         mask = self.get_structured_mask(item_seq, self.bidirectional)
-        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
+        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds)
         all_attack_masks = trm_output[1]
         attacked_output, calibrated_output = trm_output[0][-1]
         calibrated_output = self.gather_indexes(calibrated_output, item_seq_len - 1)
@@ -343,7 +343,7 @@ class AcBERT4Rec(SequentialRecommender):
     def forward(self, item_seq, _rnds=None, _keep_emb=None):
         input_emb = _front_end(self, item_seq, _keep_emb)
         mask = self.get_structured_mask(item_seq, bidirectional=True)
-        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
+        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds)
         attacked_output, calibrated_output = trm_output[0][-1]
         return attacked_output, calibrated_output, trm_output[1]
 
