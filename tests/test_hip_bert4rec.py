@@ -100,3 +100,30 @@ def test_device_cloze_training_in_a_captured_graph():
         cals.append(cal.item())
         assert torch.isfinite(att).item() and torch.isfinite(cal).item()
     assert sum(cals[-5:]) < sum(cals[:5])
+
+
+@pytest.mark.parametrize("kind,L,H,nh", [("sasrec", 200, 128, 4), ("bert", 200, 256, 4)])
+def test_baseline_configs_4_and_5_train_end_to_end(kind, L, H, nh):
+    """BASELINE configs[3] (L=200, d=128, 4 heads, causal) and configs[4] (AcBERT4Rec, bidirectional, L=200, d=256):
+    a few trainer steps through the general kernels (the gate needs gate_seq_length = L) stay finite and
+    reduce the calibrated loss."""
+    torch.manual_seed(0)
+    conf = dict(n_layers=2, n_heads=nh, hidden_size=H, inner_size=2 * H, hidden_dropout_prob=0.1, attn_dropout_prob=0.1,
+                hidden_act='gelu', layer_norm_eps=1e-12, initializer_range=0.02, loss_type='CE', combine_option='gate',
+                two_level=True, use_order=True, use_distance=True, use_position_embedding=(kind == "bert"),
+                mask_loss_weight=0.03, mask_ratio=0.2, cloze_on_device=True, gate_seq_length=L, MAX_ITEM_LIST_LENGTH=L,
+                device=DEV)
+    B, N = 16, 3000
+    cls = A.AcBERT4Rec if kind == "bert" else A.ACSASRec
+    model = cls(A.DictConfig(conf), A.ItemCount(N)).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    lens = torch.randint(20, L + 1, (B,), generator=g)
+    seq = (torch.randint(1, N, (B, L), generator=g) * (torch.arange(L)[None, :] < lens[:, None])).to(DEV)
+    batch = {"item_id_list": seq, "item_length": lens.to(DEV), "item_id": torch.randint(1, N, (B,), generator=g).to(DEV)}
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner="adam", learning_rate=2e-3), model)
+    cals = []
+    for _ in range(12):
+        att, cal = trainer.train_step(batch)
+        assert torch.isfinite(att).item() and torch.isfinite(cal).item()
+        cals.append(cal.item())
+    assert sum(cals[-3:]) < sum(cals[:3])
