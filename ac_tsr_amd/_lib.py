@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -86,6 +86,7 @@ SYMBOLS = {
     "acattn_calibrated_attention_bwd": (C.c_int, [C.POINTER(Problem), C.POINTER(BwdIO), C.c_void_p]),
     "acattn_full_sort_ce_workspace_bytes": (C.c_int64, [C.POINTER(CeProblem)]),
     "acattn_full_sort_ce_fwd": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, C.c_void_p]),
+    "acattn_full_sort_ce_fwd_dir": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, _f, C.c_void_p]),
     "acattn_full_sort_ce_bwd": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, _f, _f, C.c_void_p]),
     "acattn_dropout_add_layernorm_fwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, C.c_void_p]),
     "acattn_dropout_add_layernorm_bwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, _f, _f, _f, C.c_void_p]),

@@ -131,6 +131,15 @@ int acattn_full_sort_ce_fwd(const acattn_ce_problem* p, void* workspace, float* 
   return rc;
 }
 
+int acattn_full_sort_ce_fwd_dir(const acattn_ce_problem* p, void* workspace, float* lse, float* row_loss, float* dir,
+                                void* stream) {
+  if (int rc = check_ce(p)) return rc;
+  if (!workspace || !lse || !row_loss || !dir) return fail("workspace, lse, row_loss, dir must be non-NULL");
+  const int rc = acattn_launch_ce_fwd_dir(*p, workspace, lse, row_loss, dir, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const float* coef, void* workspace,
                             float* d_out, float* d_table, void* stream) {
   if (int rc = check_ce(p)) return rc;

@@ -151,12 +151,19 @@ __global__ void __launch_bounds__(256) ce_fwd_reduce_kernel(const acattn_ce_prob
 // ---------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------
-template <int CH, int NTILES, bool WITH_TABLE_GRAD>
+// DIR = true turns the same sweep into a FORWARD that also yields the direction of d_out: lse is not known yet, so
+// every wave exponentiates against its own running maximum, the four waves of a workgroup are brought to a common
+// maximum when their [16, CH] tiles are folded, and the workgroup emits (max, sum-exp) per row next to its slab of
+// sum_n exp(l_n - max) E_n; ce_dir_reduce_kernel finishes the soft-max across workgroups (flash-attention with
+// K = V = the item table).  `lse` / `coef` are unused then, `part` receives the (max, sum-exp) pairs.
+template <int CH, int NTILES, bool WITH_TABLE_GRAD, bool DIR = false>
 __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_problem P, const float* __restrict__ lse,
                                                             const float* __restrict__ coef,
                                                             float* __restrict__ d_out,
                                                             float* __restrict__ d_out_slab,
-                                                            float* __restrict__ d_table) {
+                                                            float* __restrict__ d_table,
+                                                            float2* __restrict__ part = nullptr) {
+  static_assert(!(DIR && WITH_TABLE_GRAD), "the forward-with-direction sweep has no table gradient");
   using C = CeCfg<CH, NTILES>;
   constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);  // transpose-scratch row stride: 16 * odd -> conflict-free column reads
   const int lane = threadIdx.x & 63;
@@ -202,8 +209,8 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
     }
     const int row = 16 * rb + c;
     const bool ok = row < B;
-    lse_next = ok ? lse[row] : 0.f;
-    cf_next = ok ? coef[row] : 0.f;
+    lse_next = (ok && !DIR) ? lse[row] : 0.f;
+    cf_next = (ok && !DIR) ? coef[row] : 0.f;
     tgt_next = ok ? (int)P.target[row] : -1;
   };
   prefetch(0);
@@ -242,14 +249,37 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         a0 = mfma16(e4[2], hf[4 * s4 + 2], a0);
         a1 = mfma16(e4[3], hf[4 * s4 + 3], a1);
       }
-      const f4 a = a0 + a1;
+      dl[t] = a0 + a1;
+    }
+    float m_w = ACATTN_NEG_INF, s_w = 0.f;  // DIR: this wave's maximum and sum-exp for batch row c
+    if (DIR) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int it = 16 * t + 4 * g + r;
-        float p = (item0 + it < N) ? __builtin_amdgcn_exp2f(a[r] * kLog2e - l2) : 0.f;
-        if (it == tgt) p -= 1.0f;
-        dl[t][r] = p * cf;
-      }
+      for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (item0 + 16 * t + 4 * g + r >= N) dl[t][r] = ACATTN_NEG_INF;
+          m_w = fmaxf(m_w, dl[t][r]);
+        }
+      m_w = quad_max(m_w);
+      const float m2 = m_w > ACATTN_NEG_INF ? m_w * kLog2e : 0.f;
+#pragma unroll
+      for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dl[t][r] = __builtin_amdgcn_exp2f(dl[t][r] * kLog2e - m2);  // exp2(-inf) = 0 past the catalogue end
+          s_w += dl[t][r];
+        }
+      s_w = quad_sum(s_w);
+    } else {
+#pragma unroll
+      for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int it = 16 * t + 4 * g + r;
+          float p = (item0 + it < N) ? __builtin_amdgcn_exp2f(dl[t][r] * kLog2e - l2) : 0.f;
+          if (it == tgt) p -= 1.0f;
+          dl[t][r] = p * cf;
+        }
     }
     // d out^T (this wave's items) = E^T . dl^T : dl registers are the B operand as they stand
     f4 dh[C::DT];
@@ -288,17 +318,39 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
     // fold the four waves' d out tiles: each wave parks its [16][CH] tile, then every thread sums one float4
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) *(f4*)(Xw + c * C::ES + 16 * dt + 4 * g) = dh[dt];
+    if (DIR && g == 0) {  // (max, sum-exp) of this wave for row c, in the pad columns of its parked tile
+      Xw[c * C::ES + CH] = m_w;
+      Xw[c * C::ES + CH + 1] = s_w;
+    }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 16 * (CH / 4); idx += blockDim.x) {
       const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
       if (16 * rb + r < B) {
         f4 sum = {0.f, 0.f, 0.f, 0.f};
+        const size_t o = (size_t)(16 * rb + r) * CH + 4 * c4;
+        if (DIR) {
+          float mw[CE_NW], m_wg = ACATTN_NEG_INF;
+#pragma unroll
+          for (int w = 0; w < CE_NW; ++w) {
+            mw[w] = X[w * XS + r * C::ES + CH];
+            m_wg = fmaxf(m_wg, mw[w]);
+          }
+          float s_wg = 0.f;
+#pragma unroll
+          for (int w = 0; w < CE_NW; ++w) {
+            const float sc = mw[w] > ACATTN_NEG_INF ? __builtin_amdgcn_exp2f((mw[w] - m_wg) * kLog2e) : 0.f;
+            sum += *(const f4*)(X + w * XS + r * C::ES + 4 * c4) * sc;
+            s_wg += X[w * XS + r * C::ES + CH + 1] * sc;
+          }
+          *(f4*)(d_out_slab + (size_t)blockIdx.x * B * CH + o) = sum;
+          if (c4 == 0) part[(size_t)blockIdx.x * B + 16 * rb + r] = float2{m_wg, s_wg};
+          continue;
+        }
 #pragma unroll
         for (int w = 0; w < CE_NW; ++w) sum += *(const f4*)(X + w * XS + r * C::ES + 4 * c4);
         // one [16, CH] tile per workgroup and row block.  Normally it goes to the workgroup's own [B, CH] slab and
         // ce_bwd_reduce_kernel folds the slabs (plain stores: 7.3 M float atomics per call cost 64 us of 330).
         // With very many rows (slabs beyond kSlabLimit) it is added to d_out with float atomics instead.
-        const size_t o = (size_t)(16 * rb + r) * CH + 4 * c4;
         if (d_out_slab) {
           *(f4*)(d_out_slab + (size_t)blockIdx.x * B * CH + o) = sum;
         } else {
@@ -348,6 +400,69 @@ __global__ void __launch_bounds__(256) ce_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int u = 0; u < 8; ++u) v += red[u][sl];
     d_out[i] = v;
+  }
+}
+
+// Finishes the forward-with-direction sweep for one batch row per workgroup:
+//   m = max_wg m_wg,  w_wg = exp(m_wg - m),  S = sum w_wg s_wg,  O = sum w_wg slab_wg[row]
+//   lse = m + log S,  row_loss = lse - out_row . E_target,  dir = O / S - E_target   (= d row_loss / d out_row)
+template <int CH>
+__global__ void __launch_bounds__(256) ce_dir_reduce_kernel(const acattn_ce_problem P, const float2* __restrict__ part,
+                                                             const float* __restrict__ slab, const int n_wg,
+                                                             float* __restrict__ lse, float* __restrict__ row_loss,
+                                                             float* __restrict__ dir) {
+  extern __shared__ float wts[];  // [n_wg] weights, then scratch
+  __shared__ float red[256];
+  const int row = blockIdx.x, B = P.B;
+  float m = ACATTN_NEG_INF;
+  for (int k = threadIdx.x; k < n_wg; k += 256) m = fmaxf(m, part[(size_t)k * B + row].x);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  float ssum = 0.f;
+  for (int k = threadIdx.x; k < n_wg; k += 256) {
+    const float2 p = part[(size_t)k * B + row];
+    const float w = p.x > ACATTN_NEG_INF ? __builtin_amdgcn_exp2f((p.x - m) * kLog2e) : 0.f;
+    wts[k] = w;
+    ssum += w * p.y;
+  }
+  red[threadIdx.x] = ssum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float S = red[0];
+  __syncthreads();
+  // O[h]: CH / 4 lanes of float4 per slab row, 256 / (CH / 4) slabs in flight per pass
+  constexpr int LPR = CH / 4, GROUPS = 256 / LPR;
+  const int c4 = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* base = slab + (size_t)row * CH + 4 * c4;
+  for (int k = grp; k < n_wg; k += GROUPS) acc += *(const f4*)(base + (size_t)k * B * CH) * wts[k];
+  float* facc = wts + n_wg;  // [GROUPS][CH]
+  *(f4*)(facc + grp * CH + 4 * c4) = acc;
+  __syncthreads();
+  if (threadIdx.x < CH) {
+    float o = 0.f;
+    for (int k = 0; k < GROUPS; ++k) o += facc[k * CH + threadIdx.x];
+    const long long tgt = P.target[row];
+    const float et = P.table[(size_t)tgt * CH + threadIdx.x];
+    dir[(size_t)row * CH + threadIdx.x] = o / S - et;
+    red[threadIdx.x] = P.out[(size_t)row * CH + threadIdx.x] * et;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float dot = 0.f;
+    for (int k = 0; k < CH; ++k) dot += red[k];
+    const float l = m + __builtin_amdgcn_logf(S) * kLn2;
+    lse[row] = l;
+    row_loss[row] = l - dot;
   }
 }
 
@@ -403,16 +518,47 @@ int launch_bwd_t(const acattn_ce_problem& p, const float* lse, const float* coef
   if (d_table) {
     auto k = ce_bwd_kernel<CH, NTILES, true>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr);
   } else {
     auto k = ce_bwd_kernel<CH, NTILES, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr);
   }
   if (slab)
     hipLaunchKernelGGL(ce_bwd_reduce_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, stream, slab, n_wg, n_out,
                        d_out);
   return (int)hipGetLastError();
+}
+
+template <int CH, int NTILES>
+int launch_fwd_dir_t(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, float* dir, hipStream_t stream) {
+  using C = CeCfg<CH, NTILES>;
+  const int n_wg = (p.N + CE_NW * C::ITEMS - 1) / (CE_NW * C::ITEMS);
+  constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);
+  constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
+  const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
+  const int64_t n_out = (int64_t)p.B * CH;
+  if (n_wg * n_out * (int64_t)sizeof(float) > kSlabLimit) return -100;
+  float* slab = (float*)ws;
+  float2* part = (float2*)(slab + (size_t)n_wg * n_out);
+  auto k = ce_bwd_kernel<CH, NTILES, false, true>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, slab, (float*)nullptr, part);
+  const size_t rlds = (size_t)(n_wg + (256 / (CH / 4)) * CH) * sizeof(float);
+  hipLaunchKernelGGL((ce_dir_reduce_kernel<CH>), dim3(p.B), dim3(256), rlds, stream, p, (const float2*)part,
+                     (const float*)slab, n_wg, lse, row_loss, dir);
+  return (int)hipGetLastError();
+}
+
+template <int CH>
+int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, float* dir, hipStream_t stream) {
+  switch (pick_tiles<CH>(p.N)) {
+    case 1: return launch_fwd_dir_t<CH, 1>(p, ws, lse, row_loss, dir, stream);
+    case 2: return launch_fwd_dir_t<CH, 2>(p, ws, lse, row_loss, dir, stream);
+    case 3: return launch_fwd_dir_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, dir, stream);
+    case 4: return launch_fwd_dir_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, dir, stream);
+    default: return launch_fwd_dir_t<CH, max_tiles<CH>()>(p, ws, lse, row_loss, dir, stream);
+  }
 }
 
 template <int CH>
@@ -425,7 +571,9 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
   const int64_t fwd = n_wg * CE_NW * p.B * (int64_t)sizeof(float2);
   // backward: one [B, CH] slab of d_out per workgroup (skipped, in favour of atomics, beyond kSlabLimit)
   const int64_t bwd = n_wg * p.B * CH * (int64_t)sizeof(float);
-  return std::max(fwd, bwd <= kSlabLimit ? bwd : 0);
+  // forward-with-direction: the same slabs plus one (max, sum-exp) pair per (workgroup, row)
+  const int64_t dirb = bwd <= kSlabLimit ? bwd + n_wg * p.B * (int64_t)sizeof(float2) : 0;
+  return std::max(fwd, std::max(bwd <= kSlabLimit ? bwd : 0, dirb));
 }
 
 template <int CH>
@@ -465,6 +613,15 @@ int acattn_launch_ce_fwd(const acattn_ce_problem& p, void* ws, float* lse, float
   switch (p.H) {
     case 64: return launch_fwd<64>(p, ws, lse, row_loss, stream);
     case 128: return launch_fwd<128>(p, ws, lse, row_loss, stream);
+  }
+  return -1;
+}
+
+int acattn_launch_ce_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, float* dir,
+                             hipStream_t stream) {
+  switch (p.H) {
+    case 64: return launch_fwd_dir<64>(p, ws, lse, row_loss, dir, stream);
+    case 128: return launch_fwd_dir<128>(p, ws, lse, row_loss, dir, stream);
   }
   return -1;
 }

@@ -140,6 +140,8 @@ int acattn_launch_rng(int B, int nh, int L, uint64_t seed, float p_drop, float* 
                       uint8_t* keep_mask, uint8_t* keep_before, hipStream_t stream);
 int64_t acattn_ce_ws_bytes(const acattn_ce_problem& p);
 int acattn_launch_ce_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream);
+int acattn_launch_ce_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, float* dir,
+                             hipStream_t stream);
 int acattn_launch_ce_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out,
                          float* d_table, hipStream_t stream);
 int acattn_launch_ln_fwd(const acattn_ln_problem& p, float* y, float* stats, hipStream_t stream);

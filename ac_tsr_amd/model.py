@@ -176,7 +176,8 @@ class ACSASRec(SequentialRecommender):
             return self.loss_fct(pos_score, neg_score)
         if output.is_cuda and ce.supported(self.hidden_size) and torch.is_grad_enabled():
             # fused: the [B, n_items] logits (205 MB at 512 x 100k) are never written
-            return ce.full_sort_cross_entropy(output, self.item_embedding.weight, pos_items)
+            # the attacked loss is differentiated for the attack transforms only (trainer.py:678-684): no table gradient
+            return ce.full_sort_cross_entropy(output, self.item_embedding.weight, pos_items, table_grad=not attack_loss)
         logits = full_sort_scores(output, self.item_embedding.weight)
         return self.loss_fct(logits, pos_items)
 
@@ -354,13 +355,13 @@ class AcBERT4Rec(SequentialRecommender):
         multi_hot[torch.arange(masked_index.size(0)), masked_index] = 1
         return multi_hot
 
-    def _cal_loss(self, seq_output, pos_items, targets):
+    def _cal_loss(self, seq_output, pos_items, targets, attack_loss=False):
         """CE over the catalogue without the mask-token row, averaged over the real masked slots
         (acbert4rec.py:201-209)."""
         table = self.item_embedding.weight[:self.n_items]
         rows = seq_output.reshape(-1, seq_output.size(-1))
         if rows.is_cuda and ce.supported(self.hidden_size) and torch.is_grad_enabled():
-            per_slot = ce.full_sort_cross_entropy_rows(rows, table, pos_items.reshape(-1))
+            per_slot = ce.full_sort_cross_entropy_rows(rows, table, pos_items.reshape(-1), table_grad=not attack_loss)
         else:
             per_slot = nn.functional.cross_entropy(full_sort_scores(rows, table), pos_items.reshape(-1), reduction='none')
         return torch.sum(per_slot * targets) / torch.sum(targets)
@@ -377,7 +378,7 @@ class AcBERT4Rec(SequentialRecommender):
         targets = (masked_index > 0).float().view(-1)
         if self.loss_type == 'BPR':
             raise NotImplementedError("the reference computes only the CE loss here (acbert4rec.py:201-209)")
-        attacked_loss = -self._cal_loss(attacked_seq_output, pos_items, targets)
+        attacked_loss = -self._cal_loss(attacked_seq_output, pos_items, targets, attack_loss=True)
         mask_penalty = torch.mean(torch.stack([_penalty(m) for m in all_attack_masks], dim=0))
         if self.trainable_mask_loss_weight:
             final_attacked_loss = attacked_loss + mask_penalty * self.mask_loss_weight[0]

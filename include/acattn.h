@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 10
+#define ACATTN_ABI_VERSION 11
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -141,6 +141,14 @@ int64_t acattn_full_sort_ce_workspace_bytes(const acattn_ce_problem* p);
 /* lse[b] = logsumexp_n(out_b . table_n);  row_loss[b] = lse[b] - out_b . table_target(b).
  * mean(row_loss) == CrossEntropyLoss(out @ table^T, target)   (acsasrec.py:118-120). */
 int acattn_full_sort_ce_fwd(const acattn_ce_problem* p, void* workspace, float* lse, float* row_loss, void* stream);
+
+/* The forward plus dir[b] = softmax_b . table - table_target(b) = d row_loss[b] / d out_b in ONE sweep of the table
+ * (flash-attention with K = V = the item table): for a loss whose table gradient is never taken -- the attacked loss
+ * of the two-pass trainer (recbole/trainer/trainer.py:678-684) -- the backward is then d_out = coef[:, None] * dir, an
+ * elementwise product, and the second sweep of acattn_full_sort_ce_bwd disappears.  Returns -100 (no error text)
+ * when B is too large for its per-workgroup slabs (~96 MB); use _fwd and _bwd then. */
+int acattn_full_sort_ce_fwd_dir(const acattn_ce_problem* p, void* workspace, float* lse, float* row_loss, float* dir,
+                                void* stream);
 
 /* Gradients of sum_b coef[b] * row_loss[b]: d_out [B,H] always; d_table [N,H] (fully overwritten) unless NULL. */
 int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const float* coef, void* workspace,

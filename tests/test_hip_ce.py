@@ -40,3 +40,28 @@ def test_fused_ce_without_table_gradient():
     ref = torch.nn.functional.cross_entropy(ref_out @ table.t(), target)
     (g_o,) = torch.autograd.grad(ref, [ref_out])
     assert (d_o - g_o).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("B,N,H", [(512, 100000, 64), (37, 1000, 64), (16, 257, 64), (130, 5003, 128), (1, 64, 64), (5, 449, 64)])
+@pytest.mark.parametrize("scale", [0.02, 1.0, 4.0])
+def test_forward_with_direction_matches_materialised_logits(B, N, H, scale):
+    """table_grad=False (acattn_full_sort_ce_fwd_dir): loss and d_out from ONE sweep, for row weights of both signs;
+    asking for the table gradient anyway still gives the right answer through the regular backward."""
+    g = torch.Generator().manual_seed(B + N + 1)
+    out = (scale * torch.randn(B, H, generator=g)).requires_grad_(True)
+    table = (scale * torch.randn(N, H, generator=g)).requires_grad_(True)
+    target = torch.randint(0, N, (B,), generator=g)
+    wrow = torch.randn(B, generator=g)
+    ref_rows = torch.nn.functional.cross_entropy(out.double() @ table.double().t(), target, reduction="none")
+    g_out, g_tab = torch.autograd.grad((ref_rows * wrow.double()).sum(), [out, table])
+    o = out.detach().to(DEV).requires_grad_(True)
+    t = table.detach().to(DEV).requires_grad_(True)
+    rows = ce.full_sort_cross_entropy_rows(o, t, target.to(DEV), table_grad=False)
+    assert (rows.detach().cpu().double() - ref_rows).abs().max() <= 1e-5 * max(1.0, ref_rows.abs().max().item())
+    (d_o,) = torch.autograd.grad((rows * wrow.to(DEV)).sum(), [o], retain_graph=True)
+    assert (d_o.cpu() - g_out.float()).abs().max() <= 1e-4 * g_out.abs().max() + 1e-9
+    d_o2, d_t = torch.autograd.grad((rows * wrow.to(DEV)).sum(), [o, t])
+    assert (d_o2.cpu() - g_out.float()).abs().max() <= 1e-4 * g_out.abs().max() + 1e-9
+    assert (d_t.cpu() - g_tab.float()).abs().max() <= 1e-4 * g_tab.abs().max() + 1e-9
+    mean = ce.full_sort_cross_entropy(o, t, target.to(DEV), table_grad=False)
+    assert abs(mean.item() - ref_rows.mean().item()) <= 1e-5 * max(1.0, abs(ref_rows.mean().item()))
