@@ -164,13 +164,13 @@ class AttackRTransformerLayer(nn.Module):
                                adversarial=True, anneal_rate=rate)
 
     def forward(self, hidden_states, attention_mask, return_attention_prob=False, return_all_attention_prob=False,
-                _rnd=None, _need_attacked=True):
+                _rnd=None, _need_attacked=True, _attack_upstream=True):
         """`_need_attacked=False` (set by the encoder for layers whose attacked output nobody can observe) skips the
         dense / LayerNorm / feed-forward tail of the attacked branch and returns None in its place."""
         att = self.attack_attention
         mq, mk, mv, qa, ka, gate_logits = projections(
             hidden_states, att.query, att.key, att.value, att.attack_query_transform, att.attack_key_transform,
-            self.gate if self.combine_option == 'gate' else None)
+            self.gate if self.combine_option == 'gate' else None, attack_upstream=_attack_upstream)
         cfg = self._config()
         core_rnd = None
         if _rnd is not None:
@@ -232,7 +232,7 @@ class AttackRTransformerEncoder(nn.Module):
             # attacked tail (dense, LayerNorm, feed-forward) of every layer but the last is unobservable and skipped
             need_attacked = output_all_encoded_layers or layer_idx == len(self.layer) - 1
             outs = layer_module(hidden_states, attention_mask, return_attention_prob, return_all_attention_prob,
-                                _rnd=rnd, _need_attacked=need_attacked)
+                                _rnd=rnd, _need_attacked=need_attacked, _attack_upstream=layer_idx > 0)
             attacked_hidden_states, calibrated_hidden_states, attack_mask, combined_attention_prob = outs[:4]
             hidden_states = calibrated_hidden_states  # layers.py:1112
             all_attack_masks.append(attack_mask)

@@ -93,12 +93,13 @@ class _Projections(torch.autograd.Function):
     gradients come from acattn_linear_wgrad.  Gradients reach exactly the leaves the six nn.Linear would feed."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg, attack_upstream):
         mq, mk, mv = F.linear(x, wq, bq), F.linear(x, wk, bk), F.linear(x, wv, bv)
         qa, ka = F.linear(mq, waq, baq), F.linear(mk, wak, bak)
         gate = F.linear(mq, wg, bg) if wg is not None else None
         ctx.save_for_backward(x, mq, mk, wq, wk, wv, waq, wak, wg if wg is not None else x.new_empty(0))
         ctx.has_gate = wg is not None
+        ctx.attack_upstream = attack_upstream
         return mq, mk, mv, qa, ka, gate
 
     @staticmethod
@@ -115,16 +116,20 @@ class _Projections(torch.autograd.Function):
                 return total
             return g @ w if total is None else total.addmm_(g, w)
 
-        # dmq / dmk are the attention node's freshly allocated dq / dk (mq and mk have no consumer outside this node
-        # and the core), so accumulating into them in place touches nothing anyone else reads
-        dmq_t = acc_(acc_(dmq, dqa, waq), dgate if ctx.has_gate else None, wg)
-        dmk_t = acc_(dmk, dka, wak)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = acc_(acc_(acc_(None, dmq_t, wq), dmk_t, wk), dmv, wv)
-            dx = dx.view_as(x) if dx is not None else None
         grads = [None] * 12
         others = not _ATTACK_PASS_ONLY  # pass 2 keeps only the attack transforms (trainer.py:678-684)
+        # In pass 2 a layer with no attack transform upstream (the first one) owes nobody an input gradient: the only
+        # things left to compute are the two attack transforms' own gradients.
+        need_dx = ctx.needs_input_grad[0] and (others or ctx.attack_upstream)
+        # dmq / dmk are the attention node's freshly allocated dq / dk (mq and mk have no consumer outside this node
+        # and the core), so accumulating into them in place touches nothing anyone else reads
+        dx = dmq_t = dmk_t = None
+        if need_dx or others:
+            dmq_t = acc_(acc_(dmq, dqa, waq), dgate if ctx.has_gate else None, wg)
+            dmk_t = acc_(dmk, dka, wak)
+        if need_dx:
+            dx = acc_(acc_(acc_(None, dmq_t, wq), dmk_t, wk), dmv, wv)
+            dx = dx.view_as(x) if dx is not None else None
         jobs = []  # (slot of the weight gradient, input, cotangent, want bias): one grouped launch pair for all of them
 
         def params(slot, inp, g, want):
@@ -142,17 +147,19 @@ class _Projections(torch.autograd.Function):
             from .ops import linear_wgrad_grouped
             for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs])):
                 grads[slot - 1], grads[slot] = gw, gb
-        return (dx, *grads)
+        return (dx, *grads, None)
 
 
-def projections(x, query, key, value, attack_query, attack_key, gate=None):
-    """(mq, mk, mv, qa, ka, gate_logits or None) of one encoder layer; see _Projections."""
+def projections(x, query, key, value, attack_query, attack_key, gate=None, attack_upstream=True):
+    """(mq, mk, mv, qa, ka, gate_logits or None) of one encoder layer; see _Projections.  `attack_upstream=False`
+    tells the node that nothing that produced `x` holds attack transforms (the first encoder layer)."""
     if not x.is_cuda or not torch.is_grad_enabled():
         mq, mk, mv = query(x), key(x), value(x)
         return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None)
     return _Projections.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
                               attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
-                              gate.weight if gate is not None else None, gate.bias if gate is not None else None)
+                              gate.weight if gate is not None else None, gate.bias if gate is not None else None,
+                              attack_upstream)
 
 
 class _FullSortScores(torch.autograd.Function):
