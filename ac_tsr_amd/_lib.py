@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -96,8 +96,8 @@ SYMBOLS = {
     "acattn_mask_penalty_fwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_void_p]),
     "acattn_mask_penalty_bwd": (C.c_int, [_f, _f, _f, C.c_int64, _f, C.c_void_p]),
     "acattn_linear_wgrad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
-    "acattn_linear_wgrad_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                               C.c_int64, C.c_int32, _f, C.c_void_p]),
+    "acattn_linear_wgrad_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int32, C.c_int64, _f, C.c_void_p]),
     "acattn_linear_wgrad": (C.c_int, [_f, _f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
     "acattn_rng_materialize": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, _f, _f, _f, _f,
                                          C.c_void_p]),

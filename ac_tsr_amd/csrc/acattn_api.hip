@@ -231,30 +231,29 @@ int acattn_mask_penalty_bwd(const float* m, const float* norm, const float* d_no
 
 int64_t acattn_linear_wgrad_workspace_bytes(int64_t M, int32_t K, int32_t N) {
   if (M < 1 || K < 1 || N < 1) return fail("M, K, N must be positive");
-  return acattn_linear_wgrad_ws_bytes(M, K, N, 1);
+  return acattn_linear_wgrad_ws_bytes(M, K, N);
 }
 
-int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, const int32_t* N, float* const* dw,
-                                float* const* db, int32_t n_items, int64_t M, int32_t K, void* workspace, void* stream) {
-  if (!x || !dy || !N || !dw || !db || !workspace) return fail("x, dy, N, dw, db and workspace must be non-NULL");
+int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, const int32_t* K, const int32_t* N,
+                                float* const* dw, float* const* db, int32_t n_items, int64_t M, void* workspace,
+                                void* stream) {
+  if (!x || !dy || !K || !N || !dw || !db || !workspace) return fail("x, dy, K, N, dw, db and workspace must be non-NULL");
   if (n_items < 1 || n_items > ACATTN_WGRAD_MAX_GROUP) return fail("n_items must lie in [1, ACATTN_WGRAD_MAX_GROUP]");
-  if (M < 1 || K < 1) return fail("M, K must be positive");
-  int n_max = 0;
+  if (M < 1) return fail("M must be positive");
   for (int i = 0; i < n_items; ++i) {
     if (!x[i] || !dy[i] || !dw[i]) return fail("every item needs x, dy and dw");
-    if (N[i] < 1) return fail("N must be positive");
-    if ((N[i] + 63) / 64 != (N[0] + 63) / 64) return fail("grouped items must agree in ceil(N / 64)");
-    n_max = std::max(n_max, (int)N[i]);
+    if (K[i] < 1 || N[i] < 1) return fail("K and N must be positive");
+    if (M * (int64_t)std::max(K[i], N[i]) >= (1LL << 40)) return fail("matrix too large");
   }
-  if (M * (int64_t)std::max((int)K, n_max) >= (1LL << 40)) return fail("matrix too large");
-  const int rc = acattn_launch_linear_wgrad(x, dy, (const int*)N, dw, db, n_items, M, K, workspace, (hipStream_t)stream);
+  const int rc = acattn_launch_linear_wgrad(x, dy, (const int*)K, (const int*)N, dw, db, n_items, M, workspace,
+                                            (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;
 }
 
 int acattn_linear_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, void* workspace, float* dw,
                         float* db, void* stream) {
-  return acattn_linear_wgrad_grouped(&x, &dy, &N, &dw, &db, 1, M, K, workspace, stream);
+  return acattn_linear_wgrad_grouped(&x, &dy, &K, &N, &dw, &db, 1, M, workspace, stream);
 }
 
 }  // extern "C"

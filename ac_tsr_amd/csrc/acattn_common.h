@@ -149,9 +149,9 @@ int acattn_launch_ln_bwd(const acattn_ln_problem& p, const float* dy, const floa
                          float* dgb_part, hipStream_t stream);
 int acattn_launch_sum_rows(const float* x, float* out, int batch, int R, int C, hipStream_t stream);
 void acattn_set_error(const char* msg);
-int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N, int n_items);
-int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, const int* N, float* const* dw,
-                               float* const* db, int n_items, int64_t M, int K, void* ws, hipStream_t stream);
+int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N);
+int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, const int* K, const int* N,
+                               float* const* dw, float* const* db, int n_items, int64_t M, void* ws, hipStream_t stream);
 int acattn_launch_embed_fwd(const acattn_embed_problem& p, float* y, float* stats, hipStream_t stream);
 int acattn_launch_embed_bwd(const acattn_embed_problem& p, const float* dy, const float* stats, int64_t padding_idx,
                             float* d_table, float* d_pos_part, float* dgb_part, hipStream_t stream);

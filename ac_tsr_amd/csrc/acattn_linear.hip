@@ -25,14 +25,18 @@ namespace {
 
 constexpr int kRegs = 64;  // accumulator registers per lane: 16 MFMA tiles x 4
 
-// Up to ACATTN_WGRAD_MAX_GROUP problems of one launch: same M, K and number of 64-wide N blocks, own operands.
-// blockIdx.z selects the item; its partials live in its own slice of the workspace.
+// Up to ACATTN_WGRAD_MAX_GROUP problems of one launch: same M, own K, N and operands.  blockIdx.z selects the
+// item; grid.y covers the largest item's 64 x 64 blocks (workgroups beyond an item's own block count leave at once);
+// an item's partials live in its own slice of the workspace (offsets in floats).
 struct WgradGroup {
   const float* x[ACATTN_WGRAD_MAX_GROUP];
   const float* dy[ACATTN_WGRAD_MAX_GROUP];
   float* dw[ACATTN_WGRAD_MAX_GROUP];
   float* db[ACATTN_WGRAD_MAX_GROUP];
+  int K[ACATTN_WGRAD_MAX_GROUP];
   int N[ACATTN_WGRAD_MAX_GROUP];
+  long long w_off[ACATTN_WGRAD_MAX_GROUP];
+  long long b_off[ACATTN_WGRAD_MAX_GROUP];
 };
 
 __device__ __forceinline__ f4 load_rows4(const float* base, int64_t row, int64_t M, int ld, int col, int ncols) {
@@ -53,15 +57,16 @@ __device__ __forceinline__ f4 load_rows4(const float* base, int64_t row, int64_t
 }
 
 template <int UNROLL>
-__global__ void __launch_bounds__(256) wgrad_partial_kernel(const WgradGroup G, const int64_t M, const int K,
-                                                             const int KB, const int NB, float* __restrict__ part_w_all,
-                                                             float* __restrict__ part_b_all) {
+__global__ void __launch_bounds__(256) wgrad_partial_kernel(const WgradGroup G, const int64_t M,
+                                                             float* __restrict__ ws) {
   const int it = blockIdx.z;
+  const int K = G.K[it], N = G.N[it];
+  const int KB = (K + 63) >> 6, NB = (N + 63) >> 6;
+  if ((int)blockIdx.y >= KB * NB) return;  // (uniform per workgroup, before any barrier)
   const float* __restrict__ x = G.x[it];
   const float* __restrict__ dy = G.dy[it];
-  const int N = G.N[it];
-  float* part_w = part_w_all + (size_t)it * KB * NB * gridDim.x * (kRegs * 64);
-  float* part_b = G.db[it] ? part_b_all + (size_t)it * NB * gridDim.x * 64 : nullptr;
+  float* part_w = ws + G.w_off[it];
+  float* part_b = G.db[it] ? ws + G.b_off[it] : nullptr;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int blk = blockIdx.y, nb = blk / KB, kb = blk - nb * KB;
@@ -122,15 +127,16 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const WgradGroup G, 
 
 // dW[n, k] for n = nb*64 + 16g + 4r + a, k = kb*64 + 4c + b lives at slot ((a*4 + b)*4 + r) * 64 + 16g + c of
 // every partial (D register r of lane 16g+c is D[4g + r][c]; tile (a, b) holds n-columns {4i + a}, k-columns {4j + b}).
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradGroup G, const float* __restrict__ part_w_all,
-                                                            const float* __restrict__ part_b_all, const int P, const int K,
-                                                            const int KB, const int NB) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradGroup G, const float* __restrict__ ws,
+                                                            const int P) {
   const int it = blockIdx.z;
-  const int N = G.N[it];
+  const int K = G.K[it], N = G.N[it];
+  const int KB = (K + 63) >> 6, NB = (N + 63) >> 6;
+  if ((int)blockIdx.y >= KB * NB) return;
   float* __restrict__ dw = G.dw[it];
   float* __restrict__ db = G.db[it];
-  const float* part_w = part_w_all + (size_t)it * KB * NB * P * (kRegs * 64);
-  const float* part_b = part_b_all + (size_t)it * NB * P * 64;
+  const float* part_w = ws + G.w_off[it];
+  const float* part_b = ws + G.b_off[it];
   const int blk = blockIdx.y, nb = blk / KB, kb = blk - nb * KB;
   // 32 slots per workgroup, 8 threads per slot; a thread sums every 8th partial with 8 loads in flight at a time
   // (the kernel is a latency chain otherwise: 4 MB spread over few workgroups), folded through LDS
@@ -186,41 +192,54 @@ int pick_partials(int64_t M, int blocks) {
 
 }  // namespace
 
-int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N, int n_items) {
-  const int KB = (K + 63) / 64, NB = (N + 63) / 64;
-  const int P = pick_partials(M, KB * NB);
-  return (int64_t)n_items * ((int64_t)KB * NB * P * kRegs * 64 + (int64_t)NB * P * 64) * (int64_t)sizeof(float);
+namespace {
+int64_t item_ws_floats(int K, int N, int P) {
+  const int64_t KB = (K + 63) / 64, NB = (N + 63) / 64;
+  return KB * NB * P * kRegs * 64 + NB * P * 64;
+}
+int group_partials(int64_t M, const int* K, const int* N, int n_items) {
+  int blocks = 1;
+  for (int i = 0; i < n_items; ++i) blocks = std::max(blocks, ((K[i] + 63) / 64) * ((N[i] + 63) / 64));
+  return pick_partials(M, blocks);
+}
+}  // namespace
+
+// upper bound for any group this problem may be launched in: P never exceeds pick_partials(M, 1)
+int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N) {
+  return item_ws_floats(K, N, pick_partials(M, 1)) * (int64_t)sizeof(float);
 }
 
-// n_items problems sharing M, K and NB = ceil(N / 64) (N itself may differ: 50 and 64 both have NB = 1)
-int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, const int* N, float* const* dw,
-                               float* const* db, int n_items, int64_t M, int K, void* ws, hipStream_t stream) {
+// n_items problems sharing M (the workspace holds sum_i acattn_linear_wgrad_ws_bytes(M, K[i], N[i]) bytes)
+int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, const int* K, const int* N,
+                               float* const* dw, float* const* db, int n_items, int64_t M, void* ws, hipStream_t stream) {
   WgradGroup G{};
-  int n_max = 0;
+  const int P = group_partials(M, K, N, n_items);
+  int blocks = 1;
+  long long off = 0;
   for (int i = 0; i < n_items; ++i) {
     G.x[i] = x[i];
     G.dy[i] = dy[i];
     G.dw[i] = dw[i];
     G.db[i] = db[i];
+    G.K[i] = K[i];
     G.N[i] = N[i];
-    n_max = std::max(n_max, N[i]);
+    const long long KB = (K[i] + 63) / 64, NB = (N[i] + 63) / 64;
+    G.w_off[i] = off;
+    G.b_off[i] = off + KB * NB * P * kRegs * 64;
+    off += item_ws_floats(K[i], N[i], P);
+    blocks = std::max(blocks, (int)(KB * NB));
   }
-  const int KB = (K + 63) / 64, NB = (n_max + 63) / 64;
-  const int P = pick_partials(M, KB * NB);
-  float* part_w = (float*)ws;
-  float* part_b = part_w + (size_t)n_items * KB * NB * P * kRegs * 64;
   // a wave's loads are all issued before its first MFMA when they fit (one HBM latency instead of several)
   const int64_t groups_per_wave = ((M + 3) / 4 + (int64_t)P * 4 - 1) / ((int64_t)P * 4);
-  const dim3 grid(P, KB * NB, n_items);
+  const dim3 grid(P, blocks, n_items);
   if (groups_per_wave > 4)
-    hipLaunchKernelGGL((wgrad_partial_kernel<7>), grid, dim3(256), 0, stream, G, M, K, KB, NB, part_w, part_b);
+    hipLaunchKernelGGL((wgrad_partial_kernel<7>), grid, dim3(256), 0, stream, G, M, (float*)ws);
   else if (groups_per_wave >= 4)
-    hipLaunchKernelGGL((wgrad_partial_kernel<4>), grid, dim3(256), 0, stream, G, M, K, KB, NB, part_w, part_b);
+    hipLaunchKernelGGL((wgrad_partial_kernel<4>), grid, dim3(256), 0, stream, G, M, (float*)ws);
   else
-    hipLaunchKernelGGL((wgrad_partial_kernel<1>), grid, dim3(256), 0, stream, G, M, K, KB, NB, part_w, part_b);
+    hipLaunchKernelGGL((wgrad_partial_kernel<1>), grid, dim3(256), 0, stream, G, M, (float*)ws);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kRegs * 2, KB * NB, n_items), dim3(256), 0, stream, G, part_w, part_b, P,
-                     K, KB, NB);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kRegs * 2, blocks, n_items), dim3(256), 0, stream, G, (const float*)ws, P);
   return (int)hipGetLastError();
 }

@@ -373,29 +373,30 @@ def mask_penalty(attack_mask: torch.Tensor) -> torch.Tensor:
 
 
 def linear_wgrad_grouped(items):
-    """[(dW, db or None), ...] for items = [(x2 [M,K], g2 [M,N_i], want_bias), ...]: items that share M, K and
-    ceil(N_i / 64) go through ONE acattn_linear_wgrad_grouped launch pair (at most WGRAD_MAX_GROUP per launch)."""
+    """[(dW, db or None), ...] for items = [(x2 [M,K_i], g2 [M,N_i], want_bias), ...]: items that share M go through
+    ONE acattn_linear_wgrad_grouped launch pair (at most WGRAD_MAX_GROUP per launch)."""
     lib = _lib.load()
     out = [None] * len(items)
     buckets = {}
     for pos, (x, g, wb) in enumerate(items):
         assert x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.shape[0] == g.shape[0]
-        buckets.setdefault((x.shape[0], x.shape[1], (g.shape[1] + 63) // 64), []).append((pos, x.contiguous(), g.contiguous(), wb))
-    for (M, K, _), members in buckets.items():
+        buckets.setdefault(x.shape[0], []).append((pos, x.contiguous(), g.contiguous(), wb))
+    for M, members in buckets.items():
         for s0 in range(0, len(members), _lib.WGRAD_MAX_GROUP):
             chunk = members[s0:s0 + _lib.WGRAD_MAX_GROUP]
             n = len(chunk)
-            n_max = max(g.shape[1] for _, _, g, _ in chunk)
             dev = chunk[0][1].device
-            ws = torch.empty(n * lib.acattn_linear_wgrad_workspace_bytes(M, K, n_max) // 4, device=dev, dtype=torch.float32)
-            dws = [torch.empty(g.shape[1], K, device=dev, dtype=torch.float32) for _, _, g, _ in chunk]
+            ws_bytes = sum(lib.acattn_linear_wgrad_workspace_bytes(M, x.shape[1], g.shape[1]) for _, x, g, _ in chunk)
+            ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
+            dws = [torch.empty(g.shape[1], x.shape[1], device=dev, dtype=torch.float32) for _, x, g, _ in chunk]
             dbs = [torch.empty(g.shape[1], device=dev, dtype=torch.float32) if wb else None for _, _, g, wb in chunk]
             arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
+            ints = lambda vals: (C.c_int32 * n)(*vals)
             _lib.check(lib.acattn_linear_wgrad_grouped(
                 arr([x.data_ptr() for _, x, _, _ in chunk]), arr([g.data_ptr() for _, _, g, _ in chunk]),
-                (C.c_int32 * n)(*[g.shape[1] for _, _, g, _ in chunk]), arr([t.data_ptr() for t in dws]),
-                arr([t.data_ptr() if t is not None else None for t in dbs]), n, M, K, _ptr(ws), _stream()),
-                "linear_wgrad_grouped")
+                ints([x.shape[1] for _, x, _, _ in chunk]), ints([g.shape[1] for _, _, g, _ in chunk]),
+                arr([t.data_ptr() for t in dws]), arr([t.data_ptr() if t is not None else None for t in dbs]), n, M,
+                _ptr(ws), _stream()), "linear_wgrad_grouped")
             for (pos, _, _, _), gw, gb in zip(chunk, dws, dbs):
                 out[pos] = (gw, gb)
     return out

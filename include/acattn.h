@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 11
+#define ACATTN_ABI_VERSION 12
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -229,13 +229,15 @@ int64_t acattn_linear_wgrad_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int acattn_linear_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, void* workspace, float* dw,
                         float* db, void* stream);
 
-/* The same for up to ACATTN_WGRAD_MAX_GROUP layers in ONE launch pair (the six projections of an encoder layer are
- * differentiated together).  Item i has operands x[i] [M,K], dy[i] [M,N[i]] and results dw[i] [N[i],K], db[i] [N[i]]
- * (db[i] may be NULL); all items share M and K and must agree in ceil(N[i] / 64).  The arrays are host arrays of
- * device pointers, read during the call.  `workspace`: n_items * acattn_linear_wgrad_workspace_bytes(M, K, max N). */
+/* The same for up to ACATTN_WGRAD_MAX_GROUP layers in ONE launch pair (the six projections of an encoder layer, or
+ * dense + the feed-forward pair of a layer's tail, are differentiated together).  Item i has operands x[i] [M,K[i]],
+ * dy[i] [M,N[i]] and results dw[i] [N[i],K[i]], db[i] [N[i]] (db[i] may be NULL); all items share M.  The arrays are
+ * host arrays (of device pointers / sizes), read during the call.
+ * `workspace`: sum_i acattn_linear_wgrad_workspace_bytes(M, K[i], N[i]) bytes. */
 #define ACATTN_WGRAD_MAX_GROUP 8
-int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, const int32_t* N, float* const* dw,
-                                float* const* db, int32_t n_items, int64_t M, int32_t K, void* workspace, void* stream);
+int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, const int32_t* K, const int32_t* N,
+                                float* const* dw, float* const* db, int32_t n_items, int64_t M, void* workspace,
+                                void* stream);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);

@@ -55,17 +55,20 @@ def test_skinny_linear_autograd_matches_torch(shape, N):
 
 
 def test_grouped_wgrad_equals_individual_calls():
-    """Six projections' worth of weight/bias gradients in one launch pair (mixed N, mixed bias flags, two N-block
-    classes that must be split into separate launches)."""
+    """Eight layers' worth of weight/bias gradients in one launch pair: mixed K, mixed N (different numbers of
+    64 x 64 blocks per item), mixed bias flags."""
     g = torch.Generator().manual_seed(9)
     M = 25600
     x, y = torch.randn(M, 64, generator=g).to(DEV), torch.randn(M, 64, generator=g).to(DEV)
     items = [(x, torch.randn(M, 64, generator=g).to(DEV), True), (x, torch.randn(M, 64, generator=g).to(DEV), False),
              (y, torch.randn(M, 50, generator=g).to(DEV), True), (x, torch.randn(M, 256, generator=g).to(DEV), True),
-             (y, torch.randn(M, 64, generator=g).to(DEV), True), (y, torch.randn(M, 200, generator=g).to(DEV), False)]
+             (y, torch.randn(M, 64, generator=g).to(DEV), True), (y, torch.randn(M, 200, generator=g).to(DEV), False),
+             (torch.randn(M, 256, generator=g).to(DEV), torch.randn(M, 64, generator=g).to(DEV), True),
+             (torch.randn(M, 50, generator=g).to(DEV), torch.randn(M, 64, generator=g).to(DEV), True)]
     got = ops.linear_wgrad_grouped(items)
     assert len(got) == len(items)
     for (xi, gi, wb), (dw, db) in zip(items, got):
         rw, rb = ops.linear_wgrad(xi, gi, wb)
-        assert torch.equal(dw, rw)
-        assert (db is None) == (not wb) and (db is None or torch.equal(db, rb))
+        # (the number of partials per block follows the largest item of a group: same sums, different association)
+        assert (dw - rw).abs().max() <= 2e-5 * rw.abs().max()
+        assert (db is None) == (not wb) and (db is None or (db - rb).abs().max() <= 2e-5 * rb.abs().max())
