@@ -27,6 +27,33 @@ def _problem(z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor) -> _lib.
     return p
 
 
+def forward_raw(z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor):
+    """(y, stats) of one acattn_dropout_add_layernorm_fwd launch; no autograd (building block of fused nodes)."""
+    p = _problem(z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor)
+    y = torch.empty_like(z)
+    stats = torch.empty(p.rows, 2, device=z.device, dtype=torch.float32)
+    _lib.check(_lib.load().acattn_dropout_add_layernorm_fwd(C.byref(p), _ptr(y), _ptr(stats), _stream()),
+               "dropout_add_layernorm_fwd")
+    return y, stats
+
+
+def backward_raw(z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor, stats, dy, want_dz=True, want_dres=True,
+                 want_gb=True):
+    """(dz, dres, partials [LN_BWD_GRID, 2, H] of (dgamma, dbeta)) of one acattn_dropout_add_layernorm_bwd launch."""
+    p = _problem(z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor)
+    dz = torch.empty_like(z) if want_dz else None
+    dres = torch.empty_like(z) if want_dres else None
+    part = torch.empty(_lib.LN_BWD_GRID, 2, z.shape[-1], device=z.device, dtype=torch.float32) if want_gb else None
+    _lib.check(_lib.load().acattn_dropout_add_layernorm_bwd(C.byref(p), _ptr(dy.contiguous()), _ptr(stats), _ptr(dz),
+                                                            _ptr(dres), _ptr(part), _stream()), "dropout_add_layernorm_bwd")
+    return dz, dres, part
+
+
+def draw_seed() -> int:
+    """One 63-bit seed for the library's counter RNG from torch's CPU generator (reproducible under manual_seed)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
 class _DropoutAddLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor):

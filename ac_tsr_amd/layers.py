@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import fused_ln, ops
+from . import tail
 from .linear import projections, skinny_linear
 from .ops import AttentionConfig, ExplicitRandomness, StructuredMask
 
@@ -183,12 +184,17 @@ class AttackRTransformerLayer(nn.Module):
             mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
             seed_tensor=ops.graph_seed_tensor() if core_rnd is None else None,
             rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
+        def branch(ctx_layer, keep_out, keep_ffn):
+            if ctx_layer.is_cuda and torch.is_grad_enabled() and tail.supported(att, self.feed_forward):
+                return tail.layer_tail(ctx_layer, hidden_states, att, self.feed_forward, keep_out, keep_ffn)
+            return self.feed_forward(att.output(ctx_layer, hidden_states, keep_out), keep_ffn)
+
         attacked_feedforward_output = None
         if _need_attacked:
-            attacked_attention_output = att.output(ctx_att, hidden_states, getattr(_rnd, "keep_out_att", None))
-            attacked_feedforward_output = self.feed_forward(attacked_attention_output, getattr(_rnd, "keep_ffn_att", None))
-        calibrated_attention_output = att.output(ctx_cal, hidden_states, getattr(_rnd, "keep_out_cal", None))
-        calibrated_feedforward_output = self.feed_forward(calibrated_attention_output, getattr(_rnd, "keep_ffn_cal", None))
+            attacked_feedforward_output = branch(ctx_att, getattr(_rnd, "keep_out_att", None),
+                                                 getattr(_rnd, "keep_ffn_att", None))
+        calibrated_feedforward_output = branch(ctx_cal, getattr(_rnd, "keep_out_cal", None),
+                                               getattr(_rnd, "keep_ffn_cal", None))
         combined_attention_prob = probs.get("calibrated_attention")
         if return_all_attention_prob:
             all_attention_prob = {

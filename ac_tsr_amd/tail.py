@@ -1,0 +1,84 @@
+"""The tail of one branch of an encoder layer as ONE autograd node:
+
+    a   = LayerNorm(dropout(dense(ctx)) + x)                  cal_adjusted_outputs, recbole/model/layers.py:681-683
+    out = LayerNorm(dropout(dense_2(gelu(dense_1(a)))) + a)   FeedForward.forward,  layers.py:790-798
+
+Forward: the same three GEMMs (hipBLASLt), torch's erf-GELU and two fused dropout+residual+LayerNorm launches.
+Backward, written out by hand: the two LayerNorm backward launches, GELU backward, three input-gradient GEMMs of
+which the one that meets the residual stream accumulates in place (beta = 1), ONE grouped launch pair for the three
+weight/bias gradients and ONE reduction for both LayerNorms' (dgamma, dbeta) partials -- instead of six autograd
+nodes with their own reductions and the elementwise adds autograd inserts where `a` fans out.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import fused_ln, linear, ops
+
+
+class _LayerTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1, p2, keep1, keep2, seed1, seed2,
+                seed_tensor):
+        c, x = c.contiguous(), x.contiguous()
+        k1 = None if keep1 is None else keep1.to(torch.uint8).contiguous()
+        k2 = None if keep2 is None else keep2.to(torch.uint8).contiguous()
+        h1 = F.linear(c, wd, bd)
+        a, st1 = fused_ln.forward_raw(h1, x, g1, b1, eps1, p1, k1, seed1, seed_tensor)
+        h2 = F.linear(a, w1, bb1)
+        act = F.gelu(h2)
+        h3 = F.linear(act, w2, bb2)
+        out, st2 = fused_ln.forward_raw(h3, a, g2, b2, eps2, p2, k2, seed2, seed_tensor)
+        empty = c.new_empty(0)
+        ctx.save_for_backward(c, x, h1, st1, a, h2, act, h3, st2, wd, g1, b1, w1, w2, g2, b2,
+                              k1 if k1 is not None else empty, k2 if k2 is not None else empty,
+                              seed_tensor if seed_tensor is not None else empty)
+        ctx.args = (eps1, eps2, p1, p2, k1 is not None, k2 is not None, seed1, seed2, seed_tensor is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (c, x, h1, st1, a, h2, act, h3, st2, wd, g1, b1, w1, w2, g2, b2, k1, k2, seed_t) = ctx.saved_tensors
+        eps1, eps2, p1, p2, has_k1, has_k2, seed1, seed2, has_seed_t = ctx.args
+        k1, k2, seed_t = (k1 if has_k1 else None), (k2 if has_k2 else None), (seed_t if has_seed_t else None)
+        params = not linear._ATTACK_PASS_ONLY  # none of these parameters is an attack transform (trainer.py:678-684)
+        two = lambda t: t.reshape(-1, t.shape[-1])
+        # feed-forward block
+        d_h3, d_a, part2 = fused_ln.backward_raw(h3, a, g2, b2, eps2, p2, k2, seed2, seed_t, st2, d_out, want_gb=params)
+        d_act = two(d_h3) @ w2
+        d_h2 = torch.ops.aten.gelu_backward(d_act.view_as(h2), h2)
+        two(d_a).addmm_(two(d_h2), w1)  # d a: residual path + through dense_1, accumulated by the GEMM
+        # attention-output block
+        need_c, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_h1, d_x, part1 = fused_ln.backward_raw(h1, x, g1, b1, eps1, p1, k1, seed1, seed_t, st1, d_a, want_dres=need_x,
+                                                 want_gb=params)
+        d_c = (two(d_h1) @ wd).view_as(c) if need_c else None
+        grads = [None] * 10  # wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2
+        if params:
+            (gwd, gbd), (gw1, gb1), (gw2, gb2) = ops.linear_wgrad_grouped(
+                [(two(c), two(d_h1), True), (two(a), two(d_h2), True), (two(act), two(d_h3), True)])
+            gb = ops.sum_rows(torch.stack((part1, part2)), 1)  # [2 norms, (dgamma, dbeta), H] in one pass
+            grads = [gwd, gbd, gb[0, 0], gb[0, 1], gw1, gb1, gw2, gb2, gb[1, 0], gb[1, 1]]
+        return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None)
+
+
+def supported(att, ffn) -> bool:
+    """The fused node covers the shipped configuration: erf-GELU, biased linears, hidden sizes of the fused LayerNorm."""
+    return (ffn.intermediate_act_fn == ffn.gelu and fused_ln.supported(att.dense.out_features)
+            and att.dense.bias is not None and ffn.dense_1.bias is not None and ffn.dense_2.bias is not None)
+
+
+def layer_tail(ctx_layer, input_tensor, att, ffn, keep_out=None, keep_ffn=None):
+    """FeedForward(attention_output(ctx_layer, input_tensor)) for one branch; `att` is the AttackRMultiHeadAttention
+    (dense, LayerNorm, out_dropout), `ffn` the FeedForward module.  keep_* feed explicit dropout masks (parity)."""
+    training = att.training
+    p1 = att.out_dropout.p if (training or keep_out is not None) else 0.0
+    p2 = ffn.dropout.p if (training or keep_ffn is not None) else 0.0
+    seed1 = fused_ln.draw_seed() if (p1 > 0 and keep_out is None) else 0
+    seed2 = fused_ln.draw_seed() if (p2 > 0 and keep_ffn is None) else 0
+    seed_t = ops.graph_seed_tensor() if (keep_out is None and keep_ffn is None) else None
+    return _LayerTail.apply(ctx_layer, input_tensor, att.dense.weight, att.dense.bias, att.LayerNorm.weight,
+                            att.LayerNorm.bias, ffn.dense_1.weight, ffn.dense_1.bias, ffn.dense_2.weight,
+                            ffn.dense_2.bias, ffn.LayerNorm.weight, ffn.LayerNorm.bias, att.LayerNorm.eps,
+                            ffn.LayerNorm.eps, p1, p2, keep_out, keep_ffn, seed1, seed2, seed_t)
