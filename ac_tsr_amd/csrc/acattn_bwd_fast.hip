@@ -73,24 +73,32 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   // ---- query-block fragments (straight from HBM) -------------------------------------------------------
   const int qb = wave, i0 = qb * 16, i = i0 + c;
   const bool row_ok = i < L;
-  float qf[KS], qaf[KS], gaf[KS], gcf[KS];
+  float qf[KS], qaf[KS];
+  // row fragment of a [B,L,H] tensor for this lane (zeros for padding rows / a NULL tensor); the cotangent fragments
+  // are fetched where they are used (L2 hits) rather than held in 2 x KS registers through the whole kernel
+  auto row_frag = [&](const float* base, float (&dst)[KS]) {
+    const size_t off = (rowbase + (row_ok ? i : 0)) * H + hoff + KS * g;
+#pragma unroll
+    for (int s4 = 0; s4 < KS / 4; ++s4) {
+      f4 t = {0.f, 0.f, 0.f, 0.f};
+      if (row_ok && base) t = *(const f4*)(base + off + 4 * s4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[4 * s4 + e] = t[e];
+    }
+  };
   {
     const size_t off = (rowbase + (row_ok ? i : 0)) * H + hoff + KS * g;
 #pragma unroll
     for (int s4 = 0; s4 < KS / 4; ++s4) {
-      f4 t = {0.f, 0.f, 0.f, 0.f}, ta = t, tga = t, tgc = t;
+      f4 t = {0.f, 0.f, 0.f, 0.f}, ta = t;
       if (row_ok) {
         t = *(const f4*)(P.q + off + 4 * s4);
         ta = *(const f4*)(P.qa + off + 4 * s4);
-        if (IO.d_ctx_attacked) tga = *(const f4*)(IO.d_ctx_attacked + off + 4 * s4);
-        if (IO.d_ctx_calibrated) tgc = *(const f4*)(IO.d_ctx_calibrated + off + 4 * s4);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         qf[4 * s4 + e] = t[e];
         qaf[4 * s4 + e] = ta[e];
-        gaf[4 * s4 + e] = tga[e];
-        gcf[4 * s4 + e] = tgc[e];
       }
     }
   }
@@ -159,7 +167,6 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   for (int j = threadIdx.x; j < 2 * DH + 8; j += blockDim.x) s_dwq[j] = 0.f;  // s_dwq and s_small are contiguous
 
   float ao = 0.f, ad = 0.f;
-  f4 wo_lo[DT], wd_lo[DT];  // query halves of the affine weights in the lane's output-column order (dq rank-1 terms)
 #pragma unroll
   for (int s4 = 0; s4 < KS / 4; ++s4) {
     const f4 a = *(const f4*)(P.w_order + KS * g + 4 * s4), d = *(const f4*)(P.w_dist + KS * g + 4 * s4);
@@ -168,11 +175,6 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       ao += qf[4 * s4 + e] * a[e];
       ad += qf[4 * s4 + e] * d[e];
     }
-  }
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) {
-    wo_lo[dt] = *(const f4*)(P.w_order + 16 * dt + 4 * g);
-    wd_lo[dt] = *(const f4*)(P.w_dist + 16 * dt + 4 * g);
   }
   ao = quad_sum(ao) + P.b_order[0];
   ad = quad_sum(ad) + P.b_dist[0];
@@ -339,6 +341,8 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     uint32_t keepA = 0, keepM = 0;  // dropout keep bits, 4 per tile
     {
       f4 dAp[NTB], Ap[NTB], nz[NTB];
+      float gaf[KS];
+      row_frag(IO.d_ctx_attacked, gaf);
       score_tiles(Vs, gaf, dAp);
       float da = 0.f;
 #pragma unroll
@@ -375,6 +379,8 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     // ---- phase 2: calibrated branch ----------------------------------------------------------------------------
     {
       f4 dAw[NTB], Ac[NTB], Aw[NTB];
+      float gcf[KS];
+      row_frag(IO.d_ctx_calibrated, gcf);
       score_tiles(Vs, gcf, dAw);
       const float* grow = P.gate_logits + (rowbase + (row_ok ? i : 0)) * L;
       float dc = 0.f;
@@ -534,7 +540,9 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         const uint32_t off = ((uint32_t)rowbase + i) * H + hoff + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          *(f4*)(IO.dq + off + 16 * dt) = oq[dt] + da_o * wo_lo[dt] + da_d * wd_lo[dt];
+          // rank-1 terms of dq: query halves of the affine weights in the lane's output-column order
+          const f4 wo_lo = *(const f4*)(P.w_order + 16 * dt + 4 * g), wd_lo = *(const f4*)(P.w_dist + 16 * dt + 4 * g);
+          *(f4*)(IO.dq + off + 16 * dt) = oq[dt] + da_o * wo_lo + da_d * wd_lo;
           *(f4*)(IO.dqa + off + 16 * dt) = oqa[dt];
         }
       }
