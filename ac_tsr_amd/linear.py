@@ -76,8 +76,8 @@ class _SkinnyLinear(torch.autograd.Function):
 
 
 def skinny_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
-    """layer(x) with the split-K weight gradient.  CPU tensors (module construction, state-dict tests)
-    take the stock path."""
+    """layer(x) whose weight / bias gradients come from acattn_linear_wgrad.  CPU tensors (module construction,
+    state-dict tests) take the stock path."""
     if not x.is_cuda or not torch.is_grad_enabled():
         return layer(x)
     return _SkinnyLinear.apply(x, layer.weight, layer.bias, getattr(layer, "_acattn_attack", False))
