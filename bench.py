@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="only the kernel roofline measurement")
     ap.add_argument("--kernel-iters", type=int, default=300)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffer, graph without optimizer) even on one GPU")
