@@ -165,9 +165,12 @@ class AttackRTransformerLayer(nn.Module):
                                adversarial=True, anneal_rate=rate)
 
     def forward(self, hidden_states, attention_mask, return_attention_prob=False, return_all_attention_prob=False,
-                _rnd=None, _need_attacked=True, _attack_upstream=True):
+                _rnd=None, _need_attacked=True, _attack_upstream=True, _rows=None):
         """`_need_attacked=False` (set by the encoder for layers whose attacked output nobody can observe) skips the
-        dense / LayerNorm / feed-forward tail of the attacked branch and returns None in its place."""
+        dense / LayerNorm / feed-forward tail of the attacked branch and returns None in its place.
+        `_rows` ([B, R] positions) makes the layer return only those positions of its two outputs ([B, R, H]): the tail
+        is position-wise, so it then runs on the selected rows alone (the models read one position per sequence of the
+        last layer, abstract_recommender.py:130-134; AcBERT4Rec the masked positions, acbert4rec.py:219-225)."""
         att = self.attack_attention
         mq, mk, mv, qa, ka, gate_logits = projections(
             hidden_states, att.query, att.key, att.value, att.attack_query_transform, att.attack_key_transform,
@@ -184,10 +187,19 @@ class AttackRTransformerLayer(nn.Module):
             mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
             seed_tensor=ops.graph_seed_tensor() if core_rnd is None else None,
             rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
+        residual = hidden_states
+        if _rows is not None:
+            index = _rows.unsqueeze(-1).expand(-1, -1, hidden_states.shape[-1])
+            pick = lambda t: None if t is None else t.gather(1, index)
+            residual = pick(hidden_states)
+        else:
+            pick = lambda t: t
+
         def branch(ctx_layer, keep_out, keep_ffn):
+            ctx_layer, keep_out, keep_ffn = pick(ctx_layer), pick(keep_out), pick(keep_ffn)
             if ctx_layer.is_cuda and torch.is_grad_enabled() and tail.supported(att, self.feed_forward):
-                return tail.layer_tail(ctx_layer, hidden_states, att, self.feed_forward, keep_out, keep_ffn)
-            return self.feed_forward(att.output(ctx_layer, hidden_states, keep_out), keep_ffn)
+                return tail.layer_tail(ctx_layer, residual, att, self.feed_forward, keep_out, keep_ffn)
+            return self.feed_forward(att.output(ctx_layer, residual, keep_out), keep_ffn)
 
         attacked_feedforward_output = None
         if _need_attacked:
@@ -223,9 +235,12 @@ class AttackRTransformerEncoder(nn.Module):
         self.layer = nn.ModuleList([copy.deepcopy(layer) for _ in range(n_layers)])
 
     def forward(self, hidden_states, attention_mask, output_all_encoded_layers=True, return_attention_prob=False,
-                return_all_attention_prob=False, _rnds: Optional[List] = None):
+                return_all_attention_prob=False, _rnds: Optional[List] = None, _last_rows=None):
         """attention_mask: the reference's dense additive tensor ([B,1,L,L] / [B,1,1,L]) or an
-        `ops.StructuredMask` (same values, derived in-kernel)."""
+        `ops.StructuredMask` (same values, derived in-kernel).  `_last_rows` ([B, R] positions, only with
+        output_all_encoded_layers=False): the last layer returns just those positions, [B, R, H]."""
+        if _last_rows is not None and output_all_encoded_layers:
+            raise ValueError("_last_rows needs output_all_encoded_layers=False")
         all_encoder_layers = []
         attacked_hidden_states = None
         calibrated_hidden_states = None
@@ -238,7 +253,8 @@ class AttackRTransformerEncoder(nn.Module):
             # attacked tail (dense, LayerNorm, feed-forward) of every layer but the last is unobservable and skipped
             need_attacked = output_all_encoded_layers or layer_idx == len(self.layer) - 1
             outs = layer_module(hidden_states, attention_mask, return_attention_prob, return_all_attention_prob,
-                                _rnd=rnd, _need_attacked=need_attacked, _attack_upstream=layer_idx > 0)
+                                _rnd=rnd, _need_attacked=need_attacked, _attack_upstream=layer_idx > 0,
+                                _rows=_last_rows if layer_idx == len(self.layer) - 1 else None)
             attacked_hidden_states, calibrated_hidden_states, attack_mask, combined_attention_prob = outs[:4]
             hidden_states = calibrated_hidden_states  # layers.py:1112
             all_attack_masks.append(attack_mask)

@@ -160,12 +160,13 @@ class ACSASRec(SequentialRecommender):
     def forward(self, item_seq, item_seq_len, is_train=False, _rnds=None, _keep_emb=None):
         input_emb = _front_end(self, item_seq, _keep_emb)
         mask = self.get_structured_mask(item_seq, self.bidirectional)
-        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds)
+        # only position item_seq_len - 1 of the last layer is read (acsasrec.py:100-103): the encoder is told, so the
+        # last layer's position-wise tail runs on B rows instead of B * L (gather and tail commute)
+        last = (item_seq_len - 1).view(-1, 1)
+        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds, _last_rows=last)
         all_attack_masks = trm_output[1]
         attacked_output, calibrated_output = trm_output[0][-1]
-        calibrated_output = self.gather_indexes(calibrated_output, item_seq_len - 1)
-        attacked_output = self.gather_indexes(attacked_output, item_seq_len - 1)
-        return attacked_output, calibrated_output, all_attack_masks
+        return attacked_output.squeeze(1), calibrated_output.squeeze(1), all_attack_masks
 
     def _cal_loss(self, output, interaction, attack_loss=False):
         pos_items = interaction[self.POS_ITEM_ID]
@@ -341,10 +342,12 @@ class AcBERT4Rec(SequentialRecommender):
         return item_seq.scatter(1, item_seq_len.view(-1, 1), self.mask_token)
 
     # ---- model ------------------------------------------------------------------------------------------------------
-    def forward(self, item_seq, _rnds=None, _keep_emb=None):
+    def forward(self, item_seq, _rnds=None, _keep_emb=None, _rows=None):
+        """(attacked [B,L,H], calibrated [B,L,H], attack masks); with `_rows` ([B,R] positions) only those positions
+        of the two outputs, [B,R,H] (see AttackRTransformerLayer.forward)."""
         input_emb = _front_end(self, item_seq, _keep_emb)
         mask = self.get_structured_mask(item_seq, bidirectional=True)
-        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds)
+        trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds, _last_rows=_rows)
         attacked_output, calibrated_output = trm_output[0][-1]
         return attacked_output, calibrated_output, trm_output[1]
 
@@ -369,12 +372,10 @@ class AcBERT4Rec(SequentialRecommender):
     def calculate_loss(self, interaction, _cloze=None, _rnds=None, _keep_emb=None):
         item_seq = interaction[self.ITEM_SEQ]
         masked_item_seq, pos_items, neg_items, masked_index = _cloze or self.reconstruct_train_data(item_seq)
-        attacked_output, calibrated_output, all_attack_masks = self.forward(masked_item_seq, _rnds=_rnds,
-                                                                            _keep_emb=_keep_emb)
-        # the reference multiplies by a one-hot matrix (acbert4rec.py:219-225): a row gather, exactly
-        index = masked_index.unsqueeze(-1).expand(-1, -1, attacked_output.size(-1))
-        attacked_seq_output = attacked_output.gather(1, index)
-        calibrated_seq_output = calibrated_output.gather(1, index)
+        # the reference multiplies the outputs by a one-hot matrix (acbert4rec.py:219-225): a row gather, exactly;
+        # the last layer's position-wise tail therefore only runs on the masked positions
+        attacked_seq_output, calibrated_seq_output, all_attack_masks = self.forward(
+            masked_item_seq, _rnds=_rnds, _keep_emb=_keep_emb, _rows=masked_index)
         targets = (masked_index > 0).float().view(-1)
         if self.loss_type == 'BPR':
             raise NotImplementedError("the reference computes only the CE loss here (acbert4rec.py:201-209)")
@@ -390,19 +391,19 @@ class AcBERT4Rec(SequentialRecommender):
     def predict(self, interaction):
         item_seq = self.reconstruct_test_data(interaction[self.ITEM_SEQ], interaction[self.ITEM_SEQ_LEN])
         item_seq_len = interaction[self.ITEM_SEQ_LEN]
-        attacked_output, calibrated_output, _ = self.forward(item_seq)
+        attacked_output, calibrated_output, _ = self.forward(item_seq, _rows=item_seq_len.view(-1, 1))
         test_item_emb = self.item_embedding(interaction[self.ITEM_ID])
-        attacked_scores = torch.mul(self.gather_indexes(attacked_output, item_seq_len), test_item_emb).sum(dim=1)
-        scores = torch.mul(self.gather_indexes(calibrated_output, item_seq_len), test_item_emb).sum(dim=1)
+        attacked_scores = torch.mul(attacked_output.squeeze(1), test_item_emb).sum(dim=1)
+        scores = torch.mul(calibrated_output.squeeze(1), test_item_emb).sum(dim=1)
         return attacked_scores, scores
 
     def full_sort_predict(self, interaction, _rnds=None):
         item_seq_len = interaction[self.ITEM_SEQ_LEN]
         item_seq = self.reconstruct_test_data(interaction[self.ITEM_SEQ], item_seq_len)
-        attacked_output, calibrated_output, _ = self.forward(item_seq, _rnds=_rnds)
+        attacked_output, calibrated_output, _ = self.forward(item_seq, _rnds=_rnds, _rows=item_seq_len.view(-1, 1))
         test_items_emb = self.item_embedding.weight[:self.n_items]  # without the mask token
-        attacked_scores = torch.matmul(self.gather_indexes(attacked_output, item_seq_len), test_items_emb.transpose(0, 1))
-        scores = torch.matmul(self.gather_indexes(calibrated_output, item_seq_len), test_items_emb.transpose(0, 1))
+        attacked_scores = torch.matmul(attacked_output.squeeze(1), test_items_emb.transpose(0, 1))
+        scores = torch.matmul(calibrated_output.squeeze(1), test_items_emb.transpose(0, 1))
         return attacked_scores, scores
 
 
