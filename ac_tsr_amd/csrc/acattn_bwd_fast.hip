@@ -551,11 +551,26 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     key_side(dMa, P.qa, aKa);
   };
 
-  switch (nt) {
-    case 1: body(std::integral_constant<int, 1>{}); break;
-    case 2: body(std::integral_constant<int, 2>{}); break;
-    case 3: body(std::integral_constant<int, 3>{}); break;
-    default: body(std::integral_constant<int, 4>{}); break;
+  // A query block none of whose rows carries a cotangent contributes nothing anywhere: its wave only writes the zeros
+  // the caller expects in dq, dqa and the gate partials (the last layer of the models is read at one position per
+  // sequence, so three of its four blocks are such blocks in the calibrated-loss pass).
+  const bool block_active = !IO.active_qblocks || IO.d_attack_mask || ((IO.active_qblocks[b] >> qb) & 1u);
+  if (block_active) {
+    switch (nt) {
+      case 1: body(std::integral_constant<int, 1>{}); break;
+      case 2: body(std::integral_constant<int, 2>{}); break;
+      case 3: body(std::integral_constant<int, 3>{}); break;
+      default: body(std::integral_constant<int, 4>{}); break;
+    }
+  } else if (row_ok) {
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t off = ((uint32_t)rowbase + i) * H + hoff + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      *(f4*)(IO.dq + off + 16 * dt) = z;
+      *(f4*)(IO.dqa + off + 16 * dt) = z;
+    }
+    for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, z);
   }
 
   // ---- key-side results and parameter partials ---------------------------------------------------------------------

@@ -100,6 +100,7 @@ class _Projections(torch.autograd.Function):
         ctx.save_for_backward(x, mq, mk, wq, wk, wv, waq, wak, wg if wg is not None else x.new_empty(0))
         ctx.has_gate = wg is not None
         ctx.attack_upstream = attack_upstream
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None in backward (handled there)
         return mq, mk, mv, qa, ka, gate
 
     @staticmethod

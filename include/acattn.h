@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 12
+#define ACATTN_ABI_VERSION 13
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -124,6 +124,10 @@ typedef struct acattn_bwd_io {
   int32_t part_stride;  /* row stride (floats) of the three partial buffers; 0 = dense (2*dh, 2*dh, 4).  With a
                            common stride the three may be column ranges of ONE [B*nh, stride] buffer, which the
                            caller then reduces in a single pass */
+  const uint32_t* active_qblocks; /* optional hint [B]: bit q set = some query row in [16q, 16q+16) of that sequence
+                           has a non-zero cotangent (d_ctx_*); blocks with a clear bit are skipped and their dq, dqa,
+                           gate partials written as zeros.  Ignored when d_attack_mask is given.  NULL = all active.
+                           A hint, not a mask: a kernel may ignore it (the skipped work multiplies zeros anyway). */
 } acattn_bwd_io;
 
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
