@@ -221,6 +221,12 @@ class AttackRTransformerLayer(nn.Module):
         return attacked_feedforward_output, calibrated_feedforward_output, attack_mask, combined_attention_prob
 
 
+# When False the models run the reference's full schedule: every layer's attacked tail, the last layer's tails on all
+# B*L positions, every input gradient -- the work DESIGN.md section 5 lists as provably without effect.  Same results
+# either way; the switch exists so that both schedules can be measured (bench.py reports both).
+PRUNE_DEAD_WORK = True
+
+
 class AttackRTransformerEncoder(nn.Module):
     """recbole/model/layers.py:1070-1131."""
 
@@ -253,7 +259,8 @@ class AttackRTransformerEncoder(nn.Module):
             # attacked tail (dense, LayerNorm, feed-forward) of every layer but the last is unobservable and skipped
             need_attacked = output_all_encoded_layers or layer_idx == len(self.layer) - 1
             outs = layer_module(hidden_states, attention_mask, return_attention_prob, return_all_attention_prob,
-                                _rnd=rnd, _need_attacked=need_attacked, _attack_upstream=layer_idx > 0,
+                                _rnd=rnd, _need_attacked=need_attacked,
+                                _attack_upstream=layer_idx > 0 or not PRUNE_DEAD_WORK,
                                 _rows=_last_rows if layer_idx == len(self.layer) - 1 else None)
             attacked_hidden_states, calibrated_hidden_states, attack_mask, combined_attention_prob = outs[:4]
             hidden_states = calibrated_hidden_states  # layers.py:1112

@@ -14,6 +14,7 @@ from enum import Enum
 import torch
 from torch import nn
 
+from . import layers
 from .layers import AttackRTransformerEncoder
 from . import ce, fused_embed
 from .linear import embedding_lookup, full_sort_scores
@@ -162,6 +163,11 @@ class ACSASRec(SequentialRecommender):
         mask = self.get_structured_mask(item_seq, self.bidirectional)
         # only position item_seq_len - 1 of the last layer is read (acsasrec.py:100-103): the encoder is told, so the
         # last layer's position-wise tail runs on B rows instead of B * L (gather and tail commute)
+        if not layers.PRUNE_DEAD_WORK:  # the reference's full schedule (acsasrec.py:99-103)
+            trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
+            attacked_output, calibrated_output = trm_output[0][-1]
+            return (self.gather_indexes(attacked_output, item_seq_len - 1),
+                    self.gather_indexes(calibrated_output, item_seq_len - 1), trm_output[1])
         last = (item_seq_len - 1).view(-1, 1)
         trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds, _last_rows=last)
         all_attack_masks = trm_output[1]
@@ -347,6 +353,13 @@ class AcBERT4Rec(SequentialRecommender):
         of the two outputs, [B,R,H] (see AttackRTransformerLayer.forward)."""
         input_emb = _front_end(self, item_seq, _keep_emb)
         mask = self.get_structured_mask(item_seq, bidirectional=True)
+        if not layers.PRUNE_DEAD_WORK:  # the reference's full schedule, rows picked afterwards (acbert4rec.py:219-225)
+            trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
+            attacked_output, calibrated_output = trm_output[0][-1]
+            if _rows is not None:
+                index = _rows.unsqueeze(-1).expand(-1, -1, attacked_output.size(-1))
+                attacked_output, calibrated_output = attacked_output.gather(1, index), calibrated_output.gather(1, index)
+            return attacked_output, calibrated_output, trm_output[1]
         trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds, _last_rows=_rows)
         attacked_output, calibrated_output = trm_output[0][-1]
         return attacked_output, calibrated_output, trm_output[1]

@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=300)
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-full-schedule", action="store_true",
+                    help="skip the extra timing of the step with the reference's full (unpruned) schedule")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffer, graph without optimizer) even on one GPU")
     return ap.parse_args()
@@ -255,6 +257,28 @@ def main():
     if not (att == att and cal == cal):
         raise SystemExit("Training loss is nan")
 
+    # The same step with the reference's full schedule (nothing that DESIGN.md section 5 lists as provably dead is
+    # skipped): reported next to `value` so that both can be judged.  Single GPU only, short, after the timed region.
+    full_ms = None
+    if world == 1 and not a.no_full_schedule:
+        from ac_tsr_amd import layers as _layers
+        _layers.PRUNE_DEAD_WORK = False
+        try:
+            full_trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model)
+            if not a.no_graph:
+                full_trainer.enable_graph(pool[0])
+            for i in range(3):
+                full_trainer.train_step(pool[i % len(pool)])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_full = max(5, a.steps // 3)
+            for i in range(n_full):
+                full_trainer.train_step(pool[i % len(pool)])
+            torch.cuda.synchronize()
+            full_ms = (time.perf_counter() - t1) / n_full * 1e3
+        finally:
+            _layers.PRUNE_DEAD_WORK = True
+
     if rank == 0:
         res = {
             "metric": "user-sequences/sec fwd+bwd, AC-SASRec L=50 d=64, 1/2/4/8 MI355X",
@@ -268,7 +292,10 @@ def main():
                             f"inner={a.inner}, CE loss, two-pass backward + Adam",
                 "global_batch": world * a.batch, "seq_len": a.seq_len, "hidden": a.hidden, "heads": a.heads,
                 "parallelism": f"dp{world}", "launch": "eager" if a.no_graph else "hipGraph replay per step",
-                "final_losses": [round(att, 4), round(cal, 4)]},
+                "final_losses": [round(att, 4), round(cal, 4)],
+                "reference_schedule": None if full_ms is None else {
+                    "ms_per_step": round(full_ms, 3), "value": round(a.batch / full_ms * 1e3, 1),
+                    "note": "same step computing also the provably dead work the reference computes (DESIGN.md 5)"}},
         }
         res["roofline"] = kernel_roofline(a, device, True, a.kernel_iters)
         res["roofline_spatial_only"] = kernel_roofline(a, device, False, a.kernel_iters)

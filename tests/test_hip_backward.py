@@ -245,3 +245,12 @@ def test_fast_training_backward_equals_general_backward(causal, p_drop, shape):
     for n in ref:
         scale = ref[n].abs().max().item()
         assert (fast[n] - ref[n]).abs().max().item() <= 2e-4 * scale + 1e-7, (n, (fast[n] - ref[n]).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("name", ["model_eval", "model_train"])
+def test_reference_schedule_switch_gives_the_same_gradients(name, monkeypatch):
+    """layers.PRUNE_DEAD_WORK = False (every tail on all positions, every layer's attacked branch, every input
+    gradient: the reference's schedule) against the same golden vectors the default schedule is checked with."""
+    from ac_tsr_amd import layers
+    monkeypatch.setattr(layers, "PRUNE_DEAD_WORK", False)
+    test_two_pass_trainer_gradients_match_reference(name)
