@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
+  const bool full = IO.attack_only == 0;  // attack_only: only dqa and dka will be read (acattn.h)
   const size_t rowbase = (size_t)b * L;
   const int hoff = h * DH;
   const size_t bh = (size_t)b * nh + h;
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         dPa[t] = du * m;
         dMa[t] = du * (p - nz[t]);
       }
-      if (IO.d_ctx_attacked) key_side(Ap, IO.d_ctx_attacked, aV);
+      if (IO.d_ctx_attacked && full) key_side(Ap, IO.d_ctx_attacked, aV);
     }
 
     // ---- phase 2: calibrated branch ----------------------------------------------------------------------------
@@ -424,14 +425,15 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
 #pragma unroll
         for (int r = 0; r < 4; ++r) gt[r] = fast_rcp(1.0f + ex2(eg[r]));
         const f4 dw = Aw[t] * (dAw[t] - dc);                       // = d A_g
-        store_seg(IO.dgate_logits + prow, t, dw * (p - Ac[t]) * (gt * (1.0f - gt)));
+        if (full) store_seg(IO.dgate_logits + prow, t, dw * (p - Ac[t]) * (gt * (1.0f - gt)));
         dPa[t] += gt * dw;
         const f4 dac = (1.0f - gt) * dw;
         dAw[t] = dac;                                              // reuse: d A_c
         r1 += hsum(Ac[t] * dac);
       }
-      for (int t = NTB; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, f4{0.f, 0.f, 0.f, 0.f});
-      if (IO.d_ctx_calibrated) key_side(Aw, IO.d_ctx_calibrated, aV);
+      if (full)
+        for (int t = NTB; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, f4{0.f, 0.f, 0.f, 0.f});
+      if (IO.d_ctx_calibrated && full) key_side(Aw, IO.d_ctx_calibrated, aV);
       r1 = quad_sum(r1);
 #pragma unroll
       for (int t = 0; t < NTB; ++t) {
@@ -532,7 +534,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
           const float* kap = Kas + (16 * t + 4 * g + r) * VS + c;
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            oq[dt] = mfma16(kp[16 * dt], dPa[t][r], oq[dt]);
+            if (full) oq[dt] = mfma16(kp[16 * dt], dPa[t][r], oq[dt]);
             oqa[dt] = mfma16(kap[16 * dt], dMa[t][r], oqa[dt]);
           }
         }
@@ -542,12 +544,12 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         for (int dt = 0; dt < DT; ++dt) {
           // rank-1 terms of dq: query halves of the affine weights in the lane's output-column order
           const f4 wo_lo = *(const f4*)(P.w_order + 16 * dt + 4 * g), wd_lo = *(const f4*)(P.w_dist + 16 * dt + 4 * g);
-          *(f4*)(IO.dq + off + 16 * dt) = oq[dt] + da_o * wo_lo + da_d * wd_lo;
+          if (full) *(f4*)(IO.dq + off + 16 * dt) = oq[dt] + da_o * wo_lo + da_d * wd_lo;
           *(f4*)(IO.dqa + off + 16 * dt) = oqa[dt];
         }
       }
     }
-    key_side(dPa, P.q, aK);
+    if (full) key_side(dPa, P.q, aK);
     key_side(dMa, P.qa, aKa);
   };
 
@@ -567,10 +569,11 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     const uint32_t off = ((uint32_t)rowbase + i) * H + hoff + 4 * g;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      *(f4*)(IO.dq + off + 16 * dt) = z;
+      if (full) *(f4*)(IO.dq + off + 16 * dt) = z;
       *(f4*)(IO.dqa + off + 16 * dt) = z;
     }
-    for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, z);
+    if (full)
+      for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, z);
   }
 
   // ---- key-side results and parameter partials ---------------------------------------------------------------------
@@ -579,10 +582,13 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     const int row = idx / (DH / 4), c4 = idx - row * (DH / 4);
     const f4 r1k = s_dco[row] * *(const f4*)(P.w_order + DH + 4 * c4) + s_dcd[row] * *(const f4*)(P.w_dist + DH + 4 * c4);
     const size_t o = (rowbase + row) * H + hoff + 4 * c4;
-    *(f4*)(IO.dk + o) = *(const f4*)(aK + row * VS + 4 * c4) + r1k;
     *(f4*)(IO.dka + o) = *(const f4*)(aKa + row * VS + 4 * c4);
-    *(f4*)(IO.dv + o) = *(const f4*)(aV + row * VS + 4 * c4);
+    if (full) {
+      *(f4*)(IO.dk + o) = *(const f4*)(aK + row * VS + 4 * c4) + r1k;
+      *(f4*)(IO.dv + o) = *(const f4*)(aV + row * VS + 4 * c4);
+    }
   }
+  if (!full) return;  // the parameter partials are not read either
   for (int d = threadIdx.x; d < 2 * DH; d += blockDim.x) {
     float wo = 0.f, wd = 0.f;
     if (d < DH) {

@@ -186,7 +186,7 @@ class AttackRTransformerLayer(nn.Module):
         ctx_att, ctx_cal, attack_mask, probs = ops.calibrated_attention(
             mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
             seed_tensor=ops.graph_seed_tensor() if core_rnd is None else None, read_rows=_rows,
-            rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
+            attack_upstream=_attack_upstream, rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
         residual = hidden_states
         if _rows is not None:
             index = _rows.unsqueeze(-1).expand(-1, -1, hidden_states.shape[-1])

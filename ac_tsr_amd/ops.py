@@ -18,6 +18,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from . import linear as linear_mod
 from ._lib import BwdIO, FwdOut, Problem
 
 
@@ -182,17 +183,21 @@ class _CalibratedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, mask,
                 cfg: AttentionConfig, p_drop: float, rnd, seed: int, want_probs: bool, seed_tensor=None,
-                read_rows=None):
+                read_rows=None, attack_upstream=True):
         lib = _lib.load()
         B, L, H = q.shape
+        ctx.attack_upstream = attack_upstream
         ctx.set_materialize_grads(False)  # an output nobody differentiated arrives as None, not as a zero tensor
         ctx.active_qblocks = None
         if read_rows is not None:
             # bit q of entry b: some read position of sequence b lies in query block q (16 rows per block)
-            blocks = torch.zeros(B, (L + 15) // 16, dtype=torch.int32, device=q.device).scatter_(
-                1, (read_rows >> 4), 1)
-            weights = (1 << torch.arange(blocks.shape[1], dtype=torch.int32, device=q.device))
-            ctx.active_qblocks = (blocks * weights).sum(dim=1, dtype=torch.int32)
+            if read_rows.shape[1] == 1:
+                ctx.active_qblocks = torch.bitwise_left_shift(1, read_rows.view(-1) >> 4).to(torch.int32)
+            else:
+                blocks = torch.zeros(B, (L + 15) // 16, dtype=torch.int32, device=q.device).scatter_(
+                    1, (read_rows >> 4), 1)
+                weights = (1 << torch.arange(blocks.shape[1], dtype=torch.int32, device=q.device))
+                ctx.active_qblocks = (blocks * weights).sum(dim=1, dtype=torch.int32)
         nh = cfg.n_heads
         keep = []
         wo = w_order.reshape(-1) if w_order is not None else None
@@ -257,7 +262,12 @@ class _CalibratedAttention(torch.autograd.Function):
         io.part_stride = width
         # the hint is only valid when the mask cotangent (which reaches every row) is absent
         io.active_qblocks = _ptr(ctx.active_qblocks) if (ctx.active_qblocks is not None and d_M is None) else None
+        # pass 2 through a layer with nothing attack-related upstream: only the attack transforms' inputs matter
+        attack_only = linear_mod._ATTACK_PASS_ONLY and not ctx.attack_upstream
+        io.attack_only = int(attack_only)
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
+        if attack_only:
+            return (None, None, None, dqa, dka) + (None,) * 16
         if dgate_part is not None:
             dgate = sum_rows(dgate_part, 1)  # the gate is shared by the heads (layers.py:887 unsqueeze(1))
         tot = sum_rows(part, 0)
@@ -269,15 +279,18 @@ class _CalibratedAttention(torch.autograd.Function):
         g_sc = small[2:3].view_as(scalar) if w_dist is not None else None
         g_rr = small[3:4].view_as(rich_ratio) if rich_ratio is not None else None
         return (dq, dk, dv, dqa, dka, dgate, g_wo, g_bo, g_wd, g_bd, g_sc, g_rr, None, None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfig, *, w_order=None, b_order=None,
                          w_dist=None, b_dist=None, scalar=None, rich_ratio=None, p_drop: float = 0.0,
                          rnd: Optional[ExplicitRandomness] = None, seed: Optional[int] = None,
                          want_probs: bool = False, seed_tensor: Optional[torch.Tensor] = None,
-                         read_rows: Optional[torch.Tensor] = None):
+                         read_rows: Optional[torch.Tensor] = None, attack_upstream: bool = True):
     """Fused core of one AttackRTransformerLayer between the projections and the output dense.
+
+    `attack_upstream=False` declares that nothing that produced q, k, v holds attack transforms (first encoder layer):
+    in pass 2 of the two-pass trainer the backward then returns only the gradients of qa and ka.
 
     `read_rows` ([B, R] int64, optional) promises that the two context outputs are only ever read at those positions
     of each sequence: the backward then skips query blocks that cannot carry a cotangent (a speed hint; results are
@@ -291,7 +304,8 @@ def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfi
     # seed_tensor (device int64[1]) is added to `seed` inside the kernels: under hipGraph capture `seed` is frozen
     # into the graph, the tensor is what changes between replays (trainer.enable_graph)
     outs = _CalibratedAttention.apply(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar,
-                                      rich_ratio, mask, cfg, p_drop, rnd, seed or 0, want_probs, seed_tensor, read_rows)
+                                      rich_ratio, mask, cfg, p_drop, rnd, seed or 0, want_probs, seed_tensor, read_rows,
+                                      attack_upstream)
     names = ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")
     probs = {n: t for n, t in zip(names, outs[3:]) if t is not None}
     return outs[0], outs[1], outs[2], probs

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 13
+#define ACATTN_ABI_VERSION 14
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -128,6 +128,9 @@ typedef struct acattn_bwd_io {
                            has a non-zero cotangent (d_ctx_*); blocks with a clear bit are skipped and their dq, dqa,
                            gate partials written as zeros.  Ignored when d_attack_mask is given.  NULL = all active.
                            A hint, not a mask: a kernel may ignore it (the skipped work multiplies zeros anyway). */
+  int32_t attack_only;  /* non-zero: the caller will read ONLY dqa and dka (pass 2 of the two-pass trainer through a
+                           layer with no attack transform upstream, recbole/trainer/trainer.py:678-684); every other
+                           output buffer must still be valid memory but may be left unwritten.  A hint like the above. */
 } acattn_bwd_io;
 
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
