@@ -41,6 +41,25 @@ class attack_pass:
         return False
 
 
+# The mirror image for pass 1 (calibrated loss, trainer.py:672-677): the attack transforms are frozen there, so their
+# weight / bias gradients would be computed and dropped.
+_CALIBRATED_PASS_ONLY = False
+
+
+class calibrated_pass:
+    """Context manager: inside it, layers tagged `_acattn_attack = True` produce no parameter gradients."""
+
+    def __enter__(self):
+        global _CALIBRATED_PASS_ONLY
+        self._prev = _CALIBRATED_PASS_ONLY
+        _CALIBRATED_PASS_ONLY = True
+
+    def __exit__(self, *exc):
+        global _CALIBRATED_PASS_ONLY
+        _CALIBRATED_PASS_ONLY = self._prev
+        return False
+
+
 def _split(m: int) -> int:
     """Number of slabs: the largest divisor of m that is <= 128 and leaves slabs of >= 128 rows."""
     best = 1
@@ -65,7 +84,7 @@ class _SkinnyLinear(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         if ctx.needs_input_grad[0]:
             gx = (g2 @ weight).view_as(x)
-        want_params = ctx.is_attack or not _ATTACK_PASS_ONLY
+        want_params = (not _CALIBRATED_PASS_ONLY) if ctx.is_attack else (not _ATTACK_PASS_ONLY)
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and want_params
         if ctx.needs_input_grad[1] and want_params:
             from .ops import linear_wgrad
@@ -140,8 +159,8 @@ class _Projections(torch.autograd.Function):
         params(1, x2, dmq_t, others)
         params(3, x2, dmk_t, others)
         params(5, x2, dmv, others)
-        params(7, mq2, dqa, True)
-        params(9, mk2, dka, True)
+        params(7, mq2, dqa, not _CALIBRATED_PASS_ONLY)
+        params(9, mk2, dka, not _CALIBRATED_PASS_ONLY)
         if ctx.has_gate:
             params(11, mq2, dgate, others)
         if jobs:

@@ -16,7 +16,7 @@ import torch
 from torch import optim
 
 from . import ops
-from .linear import attack_pass
+from .linear import attack_pass, calibrated_pass
 
 
 def is_attack_param(name: str) -> bool:
@@ -85,7 +85,8 @@ class AttackSASRecTrainer:
         # requires_grad, then walks the WHOLE graph twice (frozen leaves just drop what reaches them).
         # `backward(inputs=...)` accumulates into exactly the same leaves with the same values, and lets
         # autograd skip the branches that only feed frozen leaves (weight-gradient GEMMs, embedding scatter).
-        calibrated_loss.backward(retain_graph=attacked_loss is not None, inputs=self._others)
+        with calibrated_pass():
+            calibrated_loss.backward(retain_graph=attacked_loss is not None, inputs=self._others)
         if attacked_loss is not None:
             with attack_pass():
                 attacked_loss.backward(inputs=self._attack)
