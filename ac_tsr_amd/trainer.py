@@ -106,6 +106,7 @@ class AttackSASRecTrainer:
         step counter to its seeds so every replay draws fresh noise / dropout.  With a gradient synchronizer the
         graph ends after the second backward and the all-reduce + optimizer step stay eager."""
         assert self.device.type == 'cuda'
+        assert warmup >= 1, "at least one eager step must precede the capture (it creates the optimizer's state)"
         self._static_in = {k: v.clone() for k, v in example_interaction.items()}
         self._seed_t = torch.zeros(1, dtype=torch.int64, device=self.device)
         ops.set_graph_seed_tensor(self._seed_t)

@@ -254,3 +254,34 @@ def test_reference_schedule_switch_gives_the_same_gradients(name, monkeypatch):
     from ac_tsr_amd import layers
     monkeypatch.setattr(layers, "PRUNE_DEAD_WORK", False)
     test_two_pass_trainer_gradients_match_reference(name)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_data_parallel_code_path_matches_plain_trainer(graph):
+    """The N > 1 code path on one GPU (GradSynchronizer: store-then-pack gradients, optimizer fed from the flat buffer,
+    graph without the optimizer) updates the parameters exactly like the plain trainer given the same random state."""
+    from ac_tsr_amd import parallel
+    cfgd = dict(n_layers=2, n_heads=2, hidden_size=64, inner_size=256, hidden_dropout_prob=0.1, attn_dropout_prob=0.2,
+                hidden_act='gelu', layer_norm_eps=1e-12, initializer_range=0.02, loss_type='CE', combine_option='gate',
+                two_level=True, use_order=True, use_distance=True, mask_loss_weight=0.03)
+    g = torch.Generator().manual_seed(1)
+    B, L, N = 64, 50, 2000
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.randint(1, N, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    batch = {"item_id_list": ids.to(DEV), "item_length": lens.to(DEV), "item_id": ids[torch.arange(B), lens - 1].to(DEV)}
+    states = []
+    for use_sync in (False, True):
+        torch.manual_seed(3)
+        model = A.ACSASRec(A.DictConfig(cfgd), A.ItemCount(N)).to(DEV)
+        sync = parallel.GradSynchronizer(model.parameters()) if use_sync else None
+        trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), model, grad_sync=sync)
+        torch.manual_seed(5)  # the in-kernel RNG seeds are drawn from torch's CPU generator
+        if graph:
+            trainer.enable_graph(batch, warmup=1)  # (>= 1: Adam's state must exist before the capture)
+        for _ in range(3):
+            trainer.train_step(batch)
+        torch.cuda.synchronize()
+        states.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+        A.ops.set_graph_seed_tensor(None)
+    for k in states[0]:
+        assert (states[0][k] - states[1][k]).abs().max() <= 1e-6 * max(1.0, states[0][k].abs().max().item()), k
