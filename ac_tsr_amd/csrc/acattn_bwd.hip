@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
   const float keep_scale = has_drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
   const bool counter = P.rng_mode == ACATTN_RNG_COUNTER;
   const uint64_t seed_eff = P.seed + (P.seed_device ? *P.seed_device : 0ull);
+  const RngKey rkey = rng_key(seed_eff);
   float acc_db_o = 0.f, acc_db_d = 0.f, acc_dsc = 0.f;  // per-lane partials, reduced at the end
 
   for (int kk = 0;; ++kk) {
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
         const int j0 = 16 * t + 4 * g;
         uint32_t ka = 0xFu, km_ = 0xFu;
         if (counter) {
-          const RngGroup rg = rng_group(seed_eff, (uint32_t)(bh * L + i), (uint32_t)(4 * t + g), P.p_drop);
+          const RngGroup rg = rng_group(rkey, (uint32_t)(bh * L + i), (uint32_t)(4 * t + g), P.p_drop);
 #pragma unroll
           for (int r = 0; r < 4; ++r) nz[t][r] = rg.n[r];
           if (has_drop) {

@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   ad = quad_sum(ad) + P.b_dist[0];
   const float sc = P.scalar[0];
   const uint64_t seed_eff = P.seed + (P.seed_device ? *P.seed_device : 0ull);
+  const RngKey rkey = rng_key(seed_eff);
   __syncthreads();
 
   const unsigned long long valid_keys = __ballot(lane < L && s_km[lane] == 0.f);
@@ -348,12 +349,12 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       float da = 0.f;
 #pragma unroll
       for (int t = 0; t < NTB; ++t) {
-        const RngGroup rg = rng_group(seed_eff, rng_row, (uint32_t)(4 * t + g), P.p_drop, keep_scale);
-        nz[t] = f4{rg.n[0], rg.n[1], rg.n[2], rg.n[3]};
+        const RngGroup rg = rng_group(rkey, rng_row, (uint32_t)(4 * t + g), P.p_drop);
+        nz[t] = rg.n;
         keepA |= (has_drop ? rg.keep_after : 0xFu) << (4 * t);
         keepM |= (has_drop ? rg.keep_mask : 0xFu) << (4 * t);
-        const f4 sa = has_drop ? rg.scale_after : f4{1.f, 1.f, 1.f, 1.f};
-        const f4 sm = has_drop ? rg.scale_mask : f4{1.f, 1.f, 1.f, 1.f};
+        const f4 sa = has_drop ? keep_scale4(rg.keep_after, keep_scale) : f4{1.f, 1.f, 1.f, 1.f};
+        const f4 sm = has_drop ? keep_scale4(rg.keep_mask, keep_scale) : f4{1.f, 1.f, 1.f, 1.f};
         const f4 p = tS[t] * sa, m = tM[t] * sm;
         const f4 u2 = (p * m + nz[t] * (1.0f - m)) * kLog2e + (mask4(t) - lse_u2);
 #pragma unroll

@@ -49,9 +49,17 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + 
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based randomness (ACATTN_RNG_COUNTER).  One call yields, for the 4 consecutive keys
-// j0..j0+3 of one query row, 4 standard normals (Box-Muller) and the two dropout keep decisions
-// per key.  The stream depends only on (seed, row id, key group), so the backward kernel and
-// acattn_rng_materialize() regenerate it exactly.
+// j0..j0+3 of one query row, 4 standard normals (Box-Muller) and the dropout keep decisions of the
+// three probability tensors.  The stream depends only on (seed, row id, key group, p_drop), so the
+// backward kernel and acattn_rng_materialize() regenerate it exactly.
+//
+//   key   = two avalanche hashes of the 64-bit seed (wave-uniform: scalar unit).  A graph replay uses
+//           seed + step, and every bit of both key words changes with it: replays draw unrelated streams.
+//   x     = hash(counter ^ key.a) + key.b,   counter = row_id * 64 + group
+//   words = x, hash'(x ^ c1), hash'(x ^ c2), ...   (one multiply + one shift-xor each)
+//   normals: word k -> radius from its high 16 bits ((h + 0.5) / 65536, |n| <= 4.85), angle from its low 16
+//   keep bits: p_drop == 0.5 (every shipped configuration of the reference) -> one random bit per decision from
+//           word 2; any other p -> 16-bit fields of words 2.. compared with p * 65536.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16;
@@ -62,61 +70,93 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   return x;
 }
 
-struct RngGroup {
-  float n[4];
-  uint32_t keep_after;  // bit r set = keep
-  uint32_t keep_mask;
-  uint32_t keep_before;
-  f4 scale_after;  // keep ? keep_scale : 0   (what dropout multiplies by)
-  f4 scale_mask;
+struct RngKey {
+  uint32_t a, b;
 };
 
-// row_id = (b * n_heads + h) * L + i ; grp = j0 / 4.
-// One multiplicative hash of (seed, row, group) seeds a xorshift32 stream; 32-bit integer multiplies run at
-// quarter rate on the VALU, shifts and xors at full rate, so the stream costs ~6 full-rate ops per word.
-__device__ __forceinline__ uint32_t xs32(uint32_t& x) {
-  x ^= x << 13;
-  x ^= x >> 17;
-  x ^= x << 5;
-  return x;
+__device__ __forceinline__ RngKey rng_key(uint64_t seed) {
+  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+  RngKey k;
+  k.a = mix32(lo ^ mix32(hi ^ 0x85EBCA6Bu));
+  k.b = mix32(k.a + hi + 0x9E3779B9u);
+  return k;
 }
 
-__device__ __forceinline__ RngGroup rng_group(uint64_t seed, uint32_t row_id, uint32_t grp, float p_drop,
-                                              float keep_scale = 1.0f) {
-  const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
-  uint32_t x = mix32((row_id * 64u + grp) ^ s_lo) + s_hi;
-  x = x ? x : 0x6C078965u;  // xorshift has the fixed point 0
-  uint32_t w[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = xs32(x);
+// second-stage word hash: a multiply and a shift-xor on a value that is already well mixed
+__device__ __forceinline__ uint32_t rng_word(uint32_t x, uint32_t salt, uint32_t mul) {
+  uint32_t w = (x ^ salt) * mul;
+  return w ^ (w >> 16);
+}
+
+struct RngGroup {
+  f4 n;                 // 4 standard normals
+  uint32_t keep_after;  // bit r set = keep (4 bits each)
+  uint32_t keep_mask;
+  uint32_t keep_before;
+};
+
+// row_id = (b * n_heads + h) * L + i ; grp = j0 / 4 (< 64).
+__device__ __forceinline__ RngGroup rng_group(const RngKey key, uint32_t row_id, uint32_t grp, float p_drop) {
+  uint32_t x = (row_id * 64u + grp) ^ key.a;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  x += key.b;
+  const uint32_t w0 = x, w1 = rng_word(x, 0x68E31DA4u, 0x9E3779B1u);
   RngGroup o;
+  const uint32_t wn[2] = {w0, w1};
 #pragma unroll
-  for (int pair = 0; pair < 2; ++pair) {  // Box-Muller, 24-bit uniforms
-    const float u1 = (float)((w[2 * pair] >> 8) + 1u) * (1.0f / 16777216.0f);  // (0, 1]
-    const float u2 = (float)(w[2 * pair + 1] >> 8) * (1.0f / 16777216.0f);     // [0, 1) revolutions
-    const float rad = __builtin_amdgcn_sqrtf(-2.0f * fast_log(u1));
+  for (int pair = 0; pair < 2; ++pair) {  // Box-Muller
+    const float u1 = fmaf((float)(wn[pair] >> 16), 1.0f / 65536.0f, 0.5f / 65536.0f);  // (0, 1)
+    const float u2 = (float)(wn[pair] & 0xFFFFu) * (1.0f / 65536.0f);                  // [0, 1) revolutions
+    const float rad = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u1) * (-2.0f * 0.69314718055994530942f));
     o.n[2 * pair] = rad * __builtin_amdgcn_cosf(u2);
     o.n[2 * pair + 1] = rad * __builtin_amdgcn_sinf(u2);
   }
-  const uint32_t thr = (uint32_t)(p_drop * 65536.0f);  // keep iff 16 random bits >= thr
-  // 16-bit fields: keep_after from w4,w5; keep_mask from w6 and the low bytes left over by the uniforms;
-  // keep_before (one-level configs only, dead code elsewhere) from w7,w8
-  const uint32_t fa[4] = {w[4] & 0xFFFFu, w[4] >> 16, w[5] & 0xFFFFu, w[5] >> 16};
-  const uint32_t fm[4] = {w[6] & 0xFFFFu, w[6] >> 16, (w[0] & 0xFFu) | ((w[1] & 0xFFu) << 8),
-                          (w[2] & 0xFFu) | ((w[3] & 0xFFu) << 8)};
-  const uint32_t fb[4] = {w[7] & 0xFFFFu, w[7] >> 16, w[8] & 0xFFFFu, w[8] >> 16};
-  o.keep_after = 0;
-  o.keep_mask = 0;
-  o.keep_before = 0;
+  const uint32_t w2 = rng_word(x, 0xB5297A4Du, 0x85EBCA77u);
+  if (p_drop == 0.5f) {  // wave-uniform
+    o.keep_after = (w2 >> 4) & 0xFu;
+    o.keep_mask = (w2 >> 12) & 0xFu;
+    o.keep_before = (w2 >> 20) & 0xFu;
+  } else {
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f);  // keep iff 16 random bits >= thr
+    const uint32_t w[6] = {w2, rng_word(x, 0x1B56C4E9u, 0xC2B2AE3Du), rng_word(x, 0x7F4A7C15u, 0x27D4EB2Fu),
+                           rng_word(x, 0x94D049BBu, 0x165667B1u), rng_word(x, 0xD6E8FEB8u, 0xD3A2646Du),
+                           rng_word(x, 0x3C6EF372u, 0xFD7046C5u)};
+    uint32_t k[3] = {0, 0, 0};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    o.keep_after |= (fa[r] >= thr ? 1u : 0u) << r;
-    o.keep_mask |= (fm[r] >= thr ? 1u : 0u) << r;
-    o.keep_before |= (fb[r] >= thr ? 1u : 0u) << r;
-    o.scale_after[r] = fa[r] >= thr ? keep_scale : 0.f;
-    o.scale_mask[r] = fm[r] >= thr ? keep_scale : 0.f;
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t f = (r & 1) ? (w[2 * t + (r >> 1)] >> 16) : (w[2 * t + (r >> 1)] & 0xFFFFu);
+        k[t] |= (f >= thr ? 1u : 0u) << r;
+      }
+    }
+    o.keep_after = k[0];
+    o.keep_mask = k[1];
+    o.keep_before = k[2];
   }
   return o;
+}
+
+// keep bits -> what dropout multiplies by
+__device__ __forceinline__ f4 keep_scale4(uint32_t bits, float keep_scale) {
+  f4 s;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s[r] = ((bits >> r) & 1u) ? keep_scale : 0.f;
+  return s;
+}
+// x where the keep bit is set, +0 elsewhere, without a compare/select pair: sign-extended bit field AND value
+// Sign-extended bit `idx` of `bits` (0 or -1) as ONE v_bfe_i32.  The empty asm makes the value opaque: otherwise
+// the optimiser rewrites "mask AND value" into and + compare + select (three instructions for two).
+__device__ __forceinline__ int sbit(uint32_t bits, int idx) {
+  int m = __builtin_amdgcn_sbfe(bits, idx, 1);
+  asm("" : "+v"(m));
+  return m;
+}
+__device__ __forceinline__ float keep_and(float x, uint32_t bits, int r) {
+  return __uint_as_float(__float_as_uint(x) & (uint32_t)sbit(bits, r));
 }
 
 // Block index -> (b, head).  Workgroups b and b+8 share an XCD (round-robin dispatch), so the heads

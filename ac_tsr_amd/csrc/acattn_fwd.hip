@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
   const float keep_scale = has_drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
   const bool counter = FAST ? true : P.rng_mode == ACATTN_RNG_COUNTER;
   const uint64_t seed_eff = P.seed + (P.seed_device ? *P.seed_device : 0ull);
+  const RngKey rkey = rng_key(seed_eff);
 
   for (int kk = 0;; ++kk) {
     const int qb = (kk & 1) ? (kk + 1) * NW - 1 - wave : kk * NW + wave;  // zig-zag: balances causal work
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(256) acattn_fwd_kernel(const acattn_problem P,
           const int j0 = 16 * t + 4 * g;
           uint32_t ka = 0xFu, km_ = 0xFu, kb = 0xFu;
           if (counter) {
-            const RngGroup rg = rng_group(seed_eff, (uint32_t)(bh * L + i), (uint32_t)(4 * t + g), P.p_drop);
+            const RngGroup rg = rng_group(rkey, (uint32_t)(bh * L + i), (uint32_t)(4 * t + g), P.p_drop);
 #pragma unroll
             for (int r = 0; r < 4; ++r) nz[t][r] = rg.n[r];
             if (has_drop) {
@@ -711,7 +712,7 @@ __global__ void acattn_rng_kernel(int B, int nh, int L, uint64_t seed, float p_d
   const size_t total = (size_t)B * nh * L * groups;
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const uint32_t row = (uint32_t)(idx / groups), grp = (uint32_t)(idx % groups);
-    const RngGroup rg = rng_group(seed, row, grp, p_drop);
+    const RngGroup rg = rng_group(rng_key(seed), row, grp, p_drop);
     for (int r = 0; r < 4; ++r) {
       const int j = 4 * grp + r;
       if (j >= L) break;

@@ -63,13 +63,30 @@ __device__ __forceinline__ uint64_t sload_u64(const uint64_t* p) {
   return v;
 }
 
+// Diagnostic builds only (-DACATTN_STAMPS, tools/probe): s_memtime stamps kept in scalar registers and written
+// once at the end to the buffer passed in P.noise (unused by this kernel otherwise).  No stamp executes in the
+// product build.
+#ifdef ACATTN_STAMPS
+#define ACATTN_STAMP(k)                                                                             \
+  do {                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_[k])::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+  } while (0)
+#else
+#define ACATTN_STAMP(k)
+#endif
+
 // wait 2, expanded inside the block body after pass 1
 #define ACATTN_BODY_BEFORE_STORES                    \
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
   lds_barrier();
 
+#ifndef ACATTN_DMA_WAVES
+#define ACATTN_DMA_WAVES 4  // waves per SIMD the register allocation must leave room for
+#endif
 template <int DH, bool ADV>
-__global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_problem P, const acattn_fwd_out O) {
+__global__ void __launch_bounds__(256, ACATTN_DMA_WAVES) acattn_fwd_dma_kernel(const acattn_problem P, const acattn_fwd_out O) {
   constexpr int KS = DH / 4;
   constexpr int DT = DH / 16;
   constexpr int VS = DH + 4;
@@ -78,6 +95,10 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
   constexpr int G_J = 4;               // L * GPR <= 64 * 16 pieces = 16 chunks over 4 waves
   constexpr int NT = 4;
 
+#ifdef ACATTN_STAMPS
+  unsigned long long stamp_[12] = {};
+#endif
+  ACATTN_STAMP(0);
   const int L = P.L, H = P.H, nh = P.n_heads;
   constexpr int nT = 4, LP = 64;  // launcher: 48 < L <= 64, 4 waves
   const int GS = (L + 3) & ~3;
@@ -99,9 +120,9 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
   float* Gs = Vs + tile_f;                 // [L][GS]  (ADV only)
   float* s_co = Gs + (ADV ? L * GS : 0);   // key half of the order affine
   float* s_cd = s_co + LP;                 // key half of the distance affine
-  float* s_km = s_cd + LP;                 // key mask, exp2 domain
-  float* s_lt = s_km + LP;                 // log(d + 1)
-  float* s_w = s_lt + LP;                  // w_order [2*DH], w_dist [2*DH]
+  float* s_lt = s_cd + LP;                 // log(|d| + 1), d = -63 .. 63 (two-sided: no |.| per element)
+  const float* s_ltc = s_lt + 63;          // centre of the table
+  float* s_w = s_lt + 2 * LP;              // w_order [2*DH], w_dist [2*DH]
 
   const int qb = wave, i0 = qb * 16, i = i0 + c;
   const bool row_ok = i < L;
@@ -112,7 +133,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
   {
     const float* qp = P.q + (rowbase + (row_ok ? i : 0)) * H + hoff + KS * g;
     const float* qap = ADV ? P.qa + (rowbase + (row_ok ? i : 0)) * H + hoff + KS * g : qp;
-    const uint8_t* vp = P.key_valid + rowbase + min((int)threadIdx.x, L - 1);
+    const uint8_t* vp = P.key_valid + rowbase + min(lane, L - 1);  // every wave reads the 64 key flags itself
 #pragma unroll
     for (int s4 = 0; s4 < KS / 4; ++s4) {
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q4[s4]) : "v"(qp + 4 * s4) : "memory");
@@ -120,22 +141,21 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
     }
     asm volatile("global_load_ubyte %0, %1, off" : "=v"(valid) : "v"(vp) : "memory");
   }
-  // ---- issue, part 2: DMA ---------------------------------------------------------------------------------------
+  // ---- issue, part 2: DMA of what pass 1 needs (weights, K, Ka) ---------------------------------------------------
+  // piece p = 64 * chunk + lane of a K/Ka/V array sits at (row p / PPR, 16-byte column p % PPR); chunk q + 4 is
+  // 256 pieces further on.  One multiply-shift division for the wave's first chunk, increments after that
+  // (24-bit multiplies: the 32-bit ones run at quarter rate and this code sits in front of every load).
   {
+    int off_kv[KV_J], q_kv[KV_J];
     // affine weights: 2*DH floats each = DH/2 pieces each, one (partial) chunk, issued by every wave
     const int wp = min(lane, DH - 1);
     const float* wsrc = wp < DH / 2 ? P.w_order + 4 * wp : P.w_dist + 4 * (wp - DH / 2);
     if (lane < DH) dma16(wsrc, s_w);
     const float* kb = P.k + rowbase * H + hoff;
-    const float* vb = P.v + rowbase * H + hoff;
     const float* kab = ADV ? P.ka + rowbase * H + hoff : kb;
-    // piece p = 64 * chunk + lane of a K/Ka/V array sits at (row p / PPR, 16-byte column p % PPR); chunk q + 4 is
-    // 256 pieces further on.  One multiply-shift division for the wave's first chunk, increments after that
-    // (24-bit multiplies: the 32-bit ones run at quarter rate and this code sits in front of every load).
     constexpr uint32_t kMagic = ((1u << 20) + PPR - 1) / PPR;  // exact for p < 1024
     const int p0 = wave * 64 + lane;
     int row = (int)(__umul24((uint32_t)p0, kMagic) >> 20), ch = p0 - row * PPR;
-    int off_kv[KV_J], q_kv[KV_J];
 #pragma unroll
     for (int j = 0; j < KV_J; ++j) {
       const bool surplus = wave + 4 * j >= PPR;  // wave-uniform: repeat this wave's previous chunk
@@ -159,34 +179,12 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
 #pragma unroll
       for (int j = 0; j < KV_J; ++j) dma16(kab + off_kv[j], Kas + q_kv[j] * 256);
     }
-    // ---- behind the bar: V, then G ----
-#pragma unroll
-    for (int j = 0; j < KV_J; ++j) dma16(vb + off_kv[j], Vs + q_kv[j] * 256);
-    if (ADV) {
-      const float* gb = P.gate_logits + rowbase * L;
-      const int g_pieces = L * GPR;
-      const int g_chunks = (g_pieces + 63) >> 6;
-      const uint32_t g_magic = ((1u << 20) + GPR - 1) / GPR;  // exact for p < 1024, GPR <= 16
-      // the row's last piece may run into the next row (finite logits in pad columns are harmless); the one piece
-      // that would run past the END of the tensor is left out here and written by hand below
-      const int tail_p = ((L & 3) && b == P.B - 1) ? g_pieces - 1 : -1;
-#pragma unroll
-      for (int j = 0; j < G_J; ++j) {
-        int q = wave + 4 * j;
-        q = q < g_chunks ? q : wave;  // surplus slot: repeat the wave's first chunk (g_chunks >= 10 for L > 48)
-        const int p = q * 64 + lane;
-        const int grow = (int)(__umul24((uint32_t)p, g_magic) >> 20), gch = p - (int)__umul24((uint32_t)grow, (uint32_t)GPR);
-        if (p < g_pieces && p != tail_p) dma16(gb + (int)__umul24((uint32_t)grow, (uint32_t)L) + 4 * gch, Gs + q * 256);
-      }
-    }
   }
-  if (threadIdx.x < LP) s_lt[threadIdx.x] = logf((float)(threadIdx.x + 1));
+  if (threadIdx.x < 2 * LP - 1) s_lt[threadIdx.x] = fast_log((float)(abs((int)threadIdx.x - 63) + 1));
 
-  // ---- wait 1: q, qa, weights, K, Ka ---------------------------------------------------------------------------------
-  if (ADV)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_J + G_J) : "memory");
-  else
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_J) : "memory");
+  ACATTN_STAMP(1);
+  // ---- wait 1: q, qa, weights, K, Ka (everything issued so far) ------------------------------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   float qf[KS], qaf[KS];
 #pragma unroll
   for (int s4 = 0; s4 < KS / 4; ++s4) {
@@ -200,7 +198,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
   }
   asm volatile("" : "+v"(valid));
   lds_barrier();  // every wave's K / Ka / weight pieces are in LDS
-
+  ACATTN_STAMP(2);
   // ---- key halves of the two spatial affines, key mask; query halves (rank-1 form of layers.py:705-708,718,726) ----
   {
     const float* s_wo = s_w;
@@ -223,11 +221,6 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
       s_co[row] = -kLog2e * co;  // pre-scaled: sigmoid(o) = 1 / (1 + exp2(ao2 + co2))
       s_cd[row] = cd;
     }
-    if (threadIdx.x < LP) {
-      float km = ACATTN_NEG_INF;
-      if (threadIdx.x < L) km = (valid & 0xFFu) ? 0.f : ACATTN_MASK_FILL * kLog2e;
-      s_km[threadIdx.x] = km;
-    }
     if (ADV && (L & 3) && b == P.B - 1 && threadIdx.x < 4) {  // the gate piece the DMA left out
       const int col = (L & ~3) + threadIdx.x;
       Gs[(L - 1) * GS + col] = col < L ? P.gate_logits[(rowbase + (L - 1)) * L + col] : 0.f;
@@ -247,8 +240,45 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
   ad = quad_sum(ad) + sload_f32(P.b_dist);
   const float sc = sload_f32(P.scalar);
   lds_barrier();
+  ACATTN_STAMP(3);
+  // ---- issue, part 3: V and the gate logits, by wave 0 alone ------------------------------------------------------------
+  // They are needed by passes 2 and 3 only, so they go out AFTER the data pass 1 waits for has landed: chip-wide the
+  // first 60 % of the input bytes are then exactly the critical ones, and these travel under pass 1.  A wave that
+  // issues a DMA while the memory pipe is backed up stalls at the issue (measured: ~3k cycles for these 19
+  // instructions), so ONE wave does it: wave 0, whose causal query block has the fewest key tiles.
+  if (wave == 0) {
+    const float* vb = P.v + rowbase * H + hoff;
+    constexpr uint32_t kMagic = ((1u << 20) + PPR - 1) / PPR;
+    int row = (int)(__umul24((uint32_t)lane, kMagic) >> 20), ch = lane - row * PPR;
+#pragma unroll
+    for (int q = 0; q < PPR; ++q) {  // LP * PPR pieces = PPR chunks
+      dma16(vb + (int)__umul24((uint32_t)min(row, L - 1), (uint32_t)H) + 4 * min(ch, DH / 4 - 1), Vs + q * 256);
+      row += 64 / PPR;
+      ch += 64 % PPR;
+      if (ch >= PPR) {
+        ch -= PPR;
+        row += 1;
+      }
+    }
+    if (ADV) {
+      const float* gb = P.gate_logits + rowbase * L;
+      const int g_pieces = L * GPR;
+      const uint32_t g_magic = ((1u << 20) + GPR - 1) / GPR;  // exact for p < 1024, GPR <= 16
+      // the row's last piece may run into the next row (finite logits in pad columns are harmless); the one piece
+      // that would run past the END of the tensor is left out here and written by hand (below, before pass 1)
+      const int tail_p = ((L & 3) && b == P.B - 1) ? g_pieces - 1 : -1;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int p = q * 64 + lane;
+        if (q * 64 < g_pieces) {  // wave-uniform
+          const int grow = (int)(__umul24((uint32_t)p, g_magic) >> 20), gch = p - (int)__umul24((uint32_t)grow, (uint32_t)GPR);
+          if (p < g_pieces && p != tail_p) dma16(gb + (int)__umul24((uint32_t)grow, (uint32_t)L) + 4 * gch, Gs + q * 256);
+        }
+      }
+    }
+  }
 
-  const unsigned long long valid_keys = __ballot(lane < L && s_km[lane] == 0.f);
+  const unsigned long long valid_keys = __ballot(lane < L && (valid & 0xFFu) != 0u);
   const int first_valid = valid_keys ? __ffsll((long long)valid_keys) - 1 : L;
   const bool causal = P.causal != 0;
   const int nt_valid = valid_keys ? ((63 - __clzll((long long)valid_keys)) >> 4) + 1 : nT;
@@ -263,6 +293,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
   const uint32_t prow = ((uint32_t)bh * L + (row_ok ? i : 0)) * (uint32_t)L;
   const uint32_t rng_row = (uint32_t)(bh * L + i);
   const uint64_t seed_eff = P.seed + (P.seed_device ? sload_u64(P.seed_device) : 0ull);
+  const RngKey rkey = rng_key(seed_eff);
 
   auto store_seg = [&](float* base, int t, const f4 val) {
     const int j0 = 16 * t + 4 * g;
@@ -279,27 +310,24 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_dma_kernel(const acattn_pro
 
   const float ao2 = -kLog2e * ao;
   const float nc2 = -(hs2 * scale2);
-  auto mask4 = [&](int t) -> f4 {
-    const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
-    if (causal && (16 * t + 15 > i0)) {
-      // key 16t+4g+r lies after query i0+c  <=>  (c - 4g) + 16 (qb - t) < r : one lane constant and compares
-      // against the literals 0..3 (comparing two per-element index registers made the compiler keep -- and spill -- them)
-      const int dq = (c - 4 * g) + 16 * (qb - t);
-      f4 m;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) m[r] = (dq < r) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
-      return m;
-    }
-    return km4;
-  };
 
 #include "acattn_fwd_body.inc"
   switch (nt) {
-    case 1: body(std::integral_constant<int, 1>{}); break;
-    case 2: body(std::integral_constant<int, 2>{}); break;
-    case 3: body(std::integral_constant<int, 3>{}); break;
-    default: body(std::integral_constant<int, 4>{}); break;
+    case 1: run_body(std::integral_constant<int, 1>{}); break;
+    case 2: run_body(std::integral_constant<int, 2>{}); break;
+    case 3: run_body(std::integral_constant<int, 3>{}); break;
+    default: run_body(std::integral_constant<int, 4>{}); break;
   }
+#ifdef ACATTN_STAMPS
+  ACATTN_STAMP(9);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ACATTN_STAMP(10);
+  if (lane == 0 && P.noise) {
+    unsigned long long* sb = (unsigned long long*)P.noise + ((size_t)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) sb[k] = stamp_[k];
+  }
+#endif
 }
 
 template <int DH>

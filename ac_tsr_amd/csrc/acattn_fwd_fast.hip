@@ -56,10 +56,10 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   float* Vs = Kas + (ADV ? LP * VS : 0);
   float* s_co = Vs + LP * VS;   // key half of the order affine
   float* s_cd = s_co + LP;      // key half of the distance affine
-  float* s_km = s_cd + LP;      // key mask in the exp2 domain: 0 / -10000*log2e / -inf (j >= L)
-  float* s_lt = s_km + LP;      // log(d + 1)
+  float* s_lt = s_cd + LP;      // log(|d| + 1), d = -63 .. 63 (two-sided table, 128 floats)
+  const float* s_ltc = s_lt + 63;
   const int GS = (L + 3) & ~3;  // row stride of the staged gate logits (pad columns are zero)
-  float* Gs = s_lt + LP;        // [L][GS] gate logits of sequence b (ADV only)
+  float* Gs = s_lt + 128;       // [L][GS] gate logits of sequence b (ADV only)
 
   // ---- this wave's query block: fragments straight from HBM, issued before the staging barrier -------
   const int qb = wave, i0 = qb * 16, i = i0 + c;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   }
   const f4 w_ko = *(const f4*)(P.w_order + DH + 4 * (threadIdx.x % (DH / 4)));  // blockDim % (DH/4) == 0: same c4 every iteration
   const f4 w_kd = *(const f4*)(P.w_dist + DH + 4 * (threadIdx.x % (DH / 4)));
-  const uint8_t r_valid = (threadIdx.x < L) ? P.key_valid[rowbase + threadIdx.x] : (uint8_t)0;
+  const uint8_t r_valid = (lane < L) ? P.key_valid[rowbase + lane] : (uint8_t)0;  // every wave reads all key flags
 
   // ---- staging, step 2: registers -> LDS; the key halves of the two spatial affines fall out of the pass ----
 #pragma unroll
@@ -156,13 +156,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
       }
     }
   }
-  if (threadIdx.x < LP) {
-    const int j = threadIdx.x;
-    float km = ACATTN_NEG_INF;
-    if (j < L) km = r_valid ? 0.f : ACATTN_MASK_FILL * kLog2e;
-    s_km[j] = km;
-    s_lt[j] = logf((float)(j + 1));
-  }
+  for (int j = threadIdx.x; j < 127; j += blockDim.x) s_lt[j] = fast_log((float)(abs(j - 63) + 1));
   // query halves of the two spatial affines (rank-1 form of layers.py:705-708,718,726)
   float ao = 0.f, ad = 0.f;
 #pragma unroll
@@ -180,7 +174,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   __syncthreads();
   if (qb >= nT) return;  // (block size is 64 * nT, so this never triggers; kept as a guard)
 
-  const unsigned long long valid_keys = __ballot(lane < L && s_km[lane] == 0.f);
+  const unsigned long long valid_keys = __ballot(lane < L && r_valid != 0);
   const int first_valid = valid_keys ? __ffsll((long long)valid_keys) - 1 : L;
   const bool causal = P.causal != 0;
   // Key tiles that cannot receive probability mass are skipped: beyond the causal diagonal, and past the
@@ -198,6 +192,7 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
   const uint32_t prow = ((uint32_t)bh * L + (row_ok ? i : 0)) * (uint32_t)L;  // fits: launcher checks B*nh*L*L < 2^30
   const uint32_t rng_row = (uint32_t)(bh * L + i);
   const uint64_t seed_eff = P.seed + (P.seed_device ? *P.seed_device : 0ull);
+  const RngKey rkey = rng_key(seed_eff);
 
   auto store_seg = [&](float* base, int t, const f4 val) {
     const int j0 = 16 * t + 4 * g;
@@ -214,28 +209,12 @@ __global__ void __launch_bounds__(256, 4) acattn_fwd_fast_kernel(const acattn_pr
 
   const float ao2 = -kLog2e * ao;        // order-affine query half, pre-scaled for exp2(-o)
   const float nc2 = -(hs2 * scale2);     // -(scalar^2 / 2) / sqrt(dh) * log2e
-  // additive mask of key tile t for this lane's 4 keys (exp2 domain); only tiles that reach the causal
-  // diagonal need the per-element select
-  auto mask4 = [&](int t) -> f4 {
-    const f4 km4 = *(const f4*)(s_km + 16 * t + 4 * g);
-    if (causal && (16 * t + 15 > i0)) {
-      // key 16t+4g+r lies after query i0+c  <=>  (c - 4g) + 16 (qb - t) < r : one lane constant and compares
-      // against the literals 0..3 (comparing two per-element index registers made the compiler keep -- and spill -- them)
-      const int dq = (c - 4 * g) + 16 * (qb - t);
-      f4 m;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) m[r] = (dq < r) ? fminf(km4[r], ACATTN_MASK_FILL * kLog2e) : km4[r];
-      return m;
-    }
-    return km4;
-  };
-
 #include "acattn_fwd_body.inc"
   switch (nt) {
-    case 1: body(std::integral_constant<int, 1>{}); break;
-    case 2: body(std::integral_constant<int, 2>{}); break;
-    case 3: body(std::integral_constant<int, 3>{}); break;
-    default: body(std::integral_constant<int, 4>{}); break;
+    case 1: run_body(std::integral_constant<int, 1>{}); break;
+    case 2: run_body(std::integral_constant<int, 2>{}); break;
+    case 3: run_body(std::integral_constant<int, 3>{}); break;
+    default: run_body(std::integral_constant<int, 4>{}); break;
   }
 }
 
@@ -243,7 +222,7 @@ template <int DH>
 int launch_fast(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
   const int nT = (p.L + 15) / 16, LP = nT * 16;
   const int GS = (p.L + 3) & ~3;
-  const size_t lds = (size_t)((p.adversarial ? 3 : 2) * LP * (DH + 4) + 4 * LP + (p.adversarial ? p.L * GS : 0)) * sizeof(float);
+  const size_t lds = (size_t)((p.adversarial ? 3 : 2) * LP * (DH + 4) + 2 * LP + 128 + (p.adversarial ? p.L * GS : 0)) * sizeof(float);
   const dim3 grid(p.B * p.n_heads), block(64 * nT);
   if (lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)acattn_fwd_fast_kernel<DH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

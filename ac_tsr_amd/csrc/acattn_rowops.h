@@ -31,9 +31,9 @@ __device__ __forceinline__ f4 row_keep_scale(float p_drop, const uint8_t* keep, 
     for (int e = 0; e < 4; ++e) k[e] = kp[e] ? ks : 0.f;
     return k;
   }
-  uint32_t x = mix32(((uint32_t)row * (uint32_t)(H / 4) + (uint32_t)c4) ^ (uint32_t)seed) + (uint32_t)(seed >> 32);
-  x = x ? x : 0x6C078965u;
-  const uint32_t w0 = xs32(x), w1 = xs32(x);
+  const RngKey key = rng_key(seed);  // wave-uniform: scalar unit; every key bit changes with the replay step
+  const uint32_t x = mix32(((uint32_t)row * (uint32_t)(H / 4) + (uint32_t)c4) ^ key.a) + key.b;
+  const uint32_t w0 = x, w1 = rng_word(x, 0x68E31DA4u, 0x9E3779B1u);
   const uint32_t thr = (uint32_t)(p_drop * 65536.0f);
   k[0] = (w0 & 0xFFFFu) >= thr ? ks : 0.f;
   k[1] = (w0 >> 16) >= thr ? ks : 0.f;
