@@ -15,12 +15,13 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
 RICH = {"none": 0, "fixed": 1, "trainable": 2}
 RNG_EXPLICIT, RNG_COUNTER = 0, 1
+FWD_AUTO, FWD_STREAM, FWD_STAGED, FWD_GENERAL = 0, 1, 2, 3
 
 _f = C.c_void_p  # every device pointer travels as an integer address
 
@@ -100,6 +101,7 @@ SYMBOLS = {
     "acattn_linear_wgrad_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int32, C.c_int64, _f, C.c_void_p]),
     "acattn_linear_wgrad": (C.c_int, [_f, _f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
+    "acattn_select_forward_kernel": (C.c_int, [C.c_int]),
     "acattn_rng_materialize": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, _f, _f, _f, _f,
                                          C.c_void_p]),
 }

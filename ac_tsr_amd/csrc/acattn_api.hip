@@ -64,6 +64,8 @@ extern "C" {
 
 int acattn_abi_version(void) { return ACATTN_ABI_VERSION; }
 
+int acattn_select_forward_kernel(int which) { return acattn_fwd_kernel_choice(which); }
+
 const char* acattn_last_error(void) { return g_err; }
 
 int64_t acattn_fwd_algorithmic_bytes(const acattn_problem* p) {

@@ -33,6 +33,13 @@ __device__ __forceinline__ float quad_max(float x) {
   return fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
 }
 
+__device__ __forceinline__ uint32_t quad_or(uint32_t x) {
+  auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  x = r[0] | r[1];
+  auto s = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return s[0] | s[1];
+}
+
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   // D[16x16] += A[16x4] . B[4x16]; lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
   // D register r of lane l is D[4*(l>>4) + r][l&15].  Exact fp32 (a k-ordered fmaf chain).
@@ -159,6 +166,18 @@ __device__ __forceinline__ float keep_and(float x, uint32_t bits, int r) {
   return __uint_as_float(__float_as_uint(x) & (uint32_t)sbit(bits, r));
 }
 
+// Output stores of the streaming forward kernel: 16 bytes per lane, dword aligned, streaming ("nt") cache policy.
+// The output of a forward launch (23 MB at B = 512, L = 50) is not read again by it; with the default policy it stays
+// dirty in the XCD L2s until the kernel ends, where the write-back overlaps nothing.  Measured on the streaming
+// kernel (tools/probe, B = 512, L = 50): default 22.7 us, nt 20.6-21.5 us, write-through (sc1) 24.7 us.  The
+// LDS-staged kernels keep default-policy stores (nt cost them 1.3 us).
+// (Compiler builtins, not inline assembly: the hazard padding between an MFMA and a store of its accumulator and the
+// vmcnt bookkeeping stay the compiler's.)
+// (the pointer is only dword aligned for rows of M with L % 4 != 0; gfx950 takes dword-aligned dwordx4 accesses, and
+// the 16-byte type keeps the store one instruction)
+__device__ __forceinline__ void store_out4(float* p, const f4 v) { __builtin_nontemporal_store(v, (f4*)p); }
+__device__ __forceinline__ void store_out1(float* p, const float v) { __builtin_nontemporal_store(v, p); }
+
 // Block index -> (b, head).  Workgroups b and b+8 share an XCD (round-robin dispatch), so the heads
 // of one sequence are placed 8 blocks apart: they read the same gate-logit tile from one L2.
 // Pure speed hint; any placement gives the same results.
@@ -175,6 +194,7 @@ __device__ __forceinline__ void decode_block(int bid, int B, int nh, int& b, int
 
 // Host-side launchers (defined in the .hip files, called from acattn_api.hip).
 int acattn_launch_fwd(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
+int acattn_fwd_kernel_choice(int which);
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
 int acattn_launch_rng(int B, int nh, int L, uint64_t seed, float p_drop, float* noise, uint8_t* keep_after,
                       uint8_t* keep_mask, uint8_t* keep_before, hipStream_t stream);

@@ -17,6 +17,8 @@
 // the two first-level softmaxes; :661-672 attack mask; :917-936 adversarial calibrator; :677-680 P.V.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "acattn_common.h"
 
 namespace {
@@ -761,12 +763,34 @@ int launch_dh(const acattn_problem& p, const acattn_fwd_out& o, bool full, hipSt
 
 int acattn_launch_fwd_fast(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
 int acattn_launch_fwd_dma(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
+int acattn_launch_fwd_stream(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
+
+namespace {
+int g_fwd_kernel = ACATTN_FWD_AUTO;
+}
+int acattn_fwd_kernel_choice(int which) {
+  const int old = g_fwd_kernel;
+  if (which >= ACATTN_FWD_AUTO && which <= ACATTN_FWD_GENERAL) g_fwd_kernel = which;
+  return old;
+}
 
 int acattn_launch_fwd(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
-  const int rc_dma = acattn_launch_fwd_dma(p, o, stream);  // training hot path, 48 < L <= 64, asynchronous staging
-  if (rc_dma != -100) return rc_dma;
-  const int rc_fast = acattn_launch_fwd_fast(p, o, stream);  // training hot path (L <= 64); -100 = not applicable
-  if (rc_fast != -100) return rc_fast;
+  // training hot paths (structured mask, counter RNG, gate, two_level), -100 = not applicable:
+  //   streaming kernel (L <= 208; one wave per query block, operands straight from L2): the default, fastest at
+  //   every measured shape (B = 512: L = 50 20.8 us against 21.8 staged and 33.3 general; L = 200, H = 64: 179 us
+  //   against 536 general);
+  //   LDS-staged kernels (L <= 64; LDS-DMA staging for 48 < L, register staging below): ACATTN_FWD_STAGED
+  const int which = g_fwd_kernel;
+  if (which != ACATTN_FWD_GENERAL) {
+    if (which == ACATTN_FWD_AUTO || which == ACATTN_FWD_STREAM) {
+      const int rc_stream = acattn_launch_fwd_stream(p, o, stream);
+      if (rc_stream != -100) return rc_stream;
+    }
+    const int rc_dma = acattn_launch_fwd_dma(p, o, stream);
+    if (rc_dma != -100) return rc_dma;
+    const int rc_fast = acattn_launch_fwd_fast(p, o, stream);
+    if (rc_fast != -100) return rc_fast;
+  }
   const bool full = p.adversarial && (!p.two_level || o.after_spatial || o.before_spatial || o.perturbed_attention ||
                                       o.calibrated_attention);
   switch (p.H / p.n_heads) {

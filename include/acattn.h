@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 14
+#define ACATTN_ABI_VERSION 15
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -272,6 +272,17 @@ int acattn_calibrated_attention_bwd(const acattn_problem* p, const acattn_bwd_io
 /* Materialise the COUNTER-mode randomness for (seed, shape) so a run can be replayed in EXPLICIT mode. */
 int acattn_rng_materialize(int32_t B, int32_t n_heads, int32_t L, uint64_t seed, float p_drop, float* noise,
                            uint8_t* keep_after, uint8_t* keep_mask, uint8_t* keep_before, void* stream);
+
+/* Diagnostics / measurement: pin the forward kernel acattn_calibrated_attention_fwd dispatches to (process-wide).
+ * Every kernel computes the same function; one that does not cover the problem (options, L, rng mode) is skipped
+ * and the automatic choice applies.  Returns the previous setting. */
+enum {
+  ACATTN_FWD_AUTO = 0,    /* streaming kernel where it applies (training configuration, L <= 208), else general */
+  ACATTN_FWD_STREAM = 1,  /* acattn_fwd_stream.hip: one wave per 16-row query block, no LDS staging (L <= 208) */
+  ACATTN_FWD_STAGED = 2,  /* acattn_fwd_dma.hip / acattn_fwd_fast.hip: K, Ka, V, gate logits staged in LDS (L <= 64) */
+  ACATTN_FWD_GENERAL = 3  /* acattn_fwd.hip: every option, explicit randomness, probability dumps */
+};
+int acattn_select_forward_kernel(int which);
 
 #ifdef __cplusplus
 }

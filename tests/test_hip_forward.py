@@ -269,13 +269,33 @@ def test_error_behaviour_matches_reference():
         A.calibrated_attention(x128, x128, x128, x128, x128, gl, m, A.AttentionConfig(n_heads=1), seed=1)
 
 
+@pytest.fixture
+def forward_kernel():
+    """Pins the forward kernel (acattn_select_forward_kernel) for one test and restores the automatic choice."""
+    lib = _lib.load()
+    yield lambda which: lib.acattn_select_forward_kernel(which)
+    lib.acattn_select_forward_kernel(_lib.FWD_AUTO)
+
+
+# (B, L, H, heads, kernel): the LDS-staged kernels (L <= 64: acattn_fwd_dma.hip for 48 < L, acattn_fwd_fast.hip below)
+# and the streaming kernel (acattn_fwd_stream.hip, L <= 208).  (512, 50, 64, 2) is the shape bench.py times.
+_TUNED_CASES = [(96, 50, 64, 2, _lib.FWD_STAGED), (24, 50, 64, 4, _lib.FWD_STAGED), (16, 64, 128, 2, _lib.FWD_STAGED),
+                (8, 37, 64, 2, _lib.FWD_STAGED), (512, 50, 64, 2, _lib.FWD_STAGED),
+                (96, 50, 64, 2, _lib.FWD_STREAM), (24, 50, 64, 4, _lib.FWD_STREAM), (16, 64, 128, 2, _lib.FWD_STREAM),
+                (8, 37, 64, 2, _lib.FWD_STREAM), (512, 50, 64, 2, _lib.FWD_STREAM),
+                (6, 200, 128, 4, _lib.FWD_STREAM), (4, 200, 64, 2, _lib.FWD_STREAM), (3, 130, 256, 4, _lib.FWD_STREAM),
+                (5, 77, 64, 4, _lib.FWD_STREAM)]
+
+
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("p_drop", [0.0, 0.5])
-@pytest.mark.parametrize("shape", [(96, 50, 64, 2), (24, 50, 64, 4), (16, 64, 128, 2), (8, 37, 64, 2)])
-def test_fast_training_kernel_equals_general_kernel(causal, p_drop, shape):
-    """The tuned training kernel (counter RNG, gate, structured mask; acattn_fwd_fast.hip) against the general kernel
-    fed the same draws as explicit tensors (itself pinned to the oracle above): contexts and M."""
-    B, L, H, nh = shape
+@pytest.mark.parametrize("case", _TUNED_CASES, ids=lambda c: "B%d_L%d_H%d_h%d_k%d" % c)
+def test_fast_training_kernel_equals_general_kernel(causal, p_drop, case, forward_kernel):
+    """The tuned training kernels (counter RNG, gate, structured mask) against the general kernel fed the same draws
+    as explicit tensors (itself pinned to the oracle above): contexts and M.  Includes the exact shape, mask,
+    dropout rate and length distribution of the benchmark (B=512, L=50, H=64, 2 heads)."""
+    B, L, H, nh, which = case
+    forward_kernel(which)
     g = torch.Generator().manual_seed(7)
     q, k, v, qa, ka = (torch.randn(B, L, H, generator=g).to(DEV) for _ in range(5))
     gl = torch.randn(B, L, L, generator=g).to(DEV)

@@ -30,6 +30,20 @@
   } while (0)
 
 typedef int (*launch_fn)(const acattn_problem&, const acattn_fwd_out&, hipStream_t);
+typedef int (*abi_fn)(const acattn_problem*, const acattn_fwd_out*, void*);
+typedef int (*sel_fn)(int);
+// "libacattn.so:K" = the full library through the C ABI with forward kernel K pinned (acattn_select_forward_kernel)
+struct Variant {
+  launch_fn direct = nullptr;
+  abi_fn abi = nullptr;
+  sel_fn sel = nullptr;
+  int which = 0;
+  int operator()(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t st) const {
+    if (direct) return direct(p, o, st);
+    sel(which);
+    return abi(&p, &o, (void*)st);
+  }
+};
 
 struct Set {
   acattn_problem p;
@@ -47,7 +61,7 @@ static float* dev_randn(size_t n, std::mt19937& g, float scale = 1.f) {
 }
 
 int main(int argc, char** argv) {
-  int B = 512, L = 50, H = 64, nh = 2, adv = 1, rounds = 12, iters = 60, nsets = 6, stamps = 0, full_len = 0, balance = 0;
+  int B = 512, L = 50, H = 64, nh = 2, adv = 1, rounds = 12, iters = 60, nsets = 6, stamps = 0, full_len = 0, balance = 0, causal = 1;
   float p_drop = 0.5f;
   std::vector<std::string> libs;
   for (int i = 1; i < argc; ++i) {
@@ -63,17 +77,30 @@ int main(int argc, char** argv) {
     else if (is("-stamps")) stamps = atoi(argv[++i]);
     else if (is("-full")) full_len = atoi(argv[++i]);
     else if (is("-balance")) balance = atoi(argv[++i]);
+    else if (is("-causal")) causal = atoi(argv[++i]);
     else if (is("-pdrop")) p_drop = atof(argv[++i]);
     else libs.push_back(argv[i]);
   }
   if (libs.empty()) { fprintf(stderr, "no libs\n"); return 2; }
-  std::vector<launch_fn> fns;
+  std::vector<Variant> fns;
   for (auto& l : libs) {
-    void* h = dlopen(l.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!h) { fprintf(stderr, "dlopen %s: %s\n", l.c_str(), dlerror()); return 2; }
-    void* f = dlsym(h, "_Z21acattn_launch_fwd_dmaRK14acattn_problemRK14acattn_fwd_outP12ihipStream_t");
-    if (!f) { fprintf(stderr, "no launcher in %s\n", l.c_str()); return 2; }
-    fns.push_back((launch_fn)f);
+    std::string path = l;
+    Variant v;
+    const size_t colon = l.rfind(':');
+    if (colon != std::string::npos && colon + 2 == l.size()) { path = l.substr(0, colon); v.which = l[colon + 1] - '0'; }
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "dlopen %s: %s\n", path.c_str(), dlerror()); return 2; }
+    if (path != l) {
+      v.abi = (abi_fn)dlsym(h, "acattn_calibrated_attention_fwd");
+      v.sel = (sel_fn)dlsym(h, "acattn_select_forward_kernel");
+      if (!v.abi || !v.sel) { fprintf(stderr, "no C ABI in %s\n", path.c_str()); return 2; }
+    } else {
+      void* f = dlsym(h, "_Z21acattn_launch_fwd_dmaRK14acattn_problemRK14acattn_fwd_outP12ihipStream_t");
+      if (!f) f = dlsym(h, "_Z24acattn_launch_fwd_streamRK14acattn_problemRK14acattn_fwd_outP12ihipStream_t");
+      if (!f) { fprintf(stderr, "no launcher in %s\n", path.c_str()); return 2; }
+      v.direct = (launch_fn)f;
+    }
+    fns.push_back(v);
   }
   std::mt19937 g(42);
   const int dh = H / nh;
@@ -113,7 +140,7 @@ int main(int argc, char** argv) {
     uint8_t* kvd;
     CK(hipMalloc(&kvd, kv.size()));
     CK(hipMemcpy(kvd, kv.data(), kv.size(), hipMemcpyHostToDevice));
-    p.mask_mode = ACATTN_MASK_STRUCTURED; p.causal = 1; p.key_valid = kvd;
+    p.mask_mode = ACATTN_MASK_STRUCTURED; p.causal = causal; p.key_valid = kvd;
     p.w_order = w_order; p.b_order = b_order; p.w_dist = w_dist; p.b_dist = b_dist; p.scalar = scalar;
     p.adversarial = adv; p.two_level = 1; p.rng_mode = ACATTN_RNG_COUNTER; p.p_drop = p_drop; p.seed = 1234 + s;
     float* cc; CK(hipMalloc(&cc, n_lh * 4)); o.ctx_calibrated = cc;
