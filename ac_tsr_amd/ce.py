@@ -10,7 +10,8 @@ import ctypes as C
 
 import torch
 
-from . import _lib, linear
+from . import _lib
+from .state import DEFAULT as _DEFAULT_STATE
 from .ops import _need_cuda, _ptr, _stream
 
 
@@ -24,7 +25,8 @@ def _problem(out, table, target) -> _lib.CeProblem:
 
 class _FullSortCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, out, table, target):
+    def forward(ctx, out, table, target, state):
+        ctx.state = state
         for name, t in (("output", out), ("item table", table)):
             _need_cuda(name, t)
         _need_cuda("target", target, torch.int64)
@@ -51,11 +53,11 @@ class _FullSortCE(torch.autograd.Function):
         coef = d_row_loss.contiguous()
         d_out = torch.empty_like(out)
         # the item table is not an attack parameter: its gradient is dropped in the attacked-loss pass
-        want_table = ctx.needs_input_grad[1] and not linear._ATTACK_PASS_ONLY
+        want_table = ctx.needs_input_grad[1] and not ctx.state.attack_pass_only
         d_table = torch.empty_like(table) if want_table else None
         _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(coef), _ptr(ws), _ptr(d_out), _ptr(d_table),
                                                _stream()), "full_sort_ce_bwd")
-        return d_out, d_table, None
+        return d_out, d_table, None, None
 
 
 class _FullSortCEDir(torch.autograd.Function):
@@ -65,7 +67,8 @@ class _FullSortCEDir(torch.autograd.Function):
     sweep of the catalogue.  If a caller does ask for the table gradient, it is computed by the regular backward."""
 
     @staticmethod
-    def forward(ctx, out, table, target):
+    def forward(ctx, out, table, target, state):
+        ctx.state = state
         for name, t in (("output", out), ("item table", table)):
             _need_cuda(name, t)
         _need_cuda("target", target, torch.int64)
@@ -92,9 +95,9 @@ class _FullSortCEDir(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_row_loss):
         out, table, target, lse, direction = ctx.saved_tensors
-        want_table = ctx.needs_input_grad[1] and not linear._ATTACK_PASS_ONLY
+        want_table = ctx.needs_input_grad[1] and not ctx.state.attack_pass_only
         if ctx.has_dir and not want_table:
-            return direction * d_row_loss.unsqueeze(1), None, None
+            return direction * d_row_loss.unsqueeze(1), None, None, None
         lib = _lib.load()
         p = _problem(out, table, target)
         ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=out.device)
@@ -102,22 +105,22 @@ class _FullSortCEDir(torch.autograd.Function):
         d_table = torch.empty_like(table) if want_table else None
         _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_row_loss.contiguous()), _ptr(ws), _ptr(d_out),
                                                _ptr(d_table), _stream()), "full_sort_ce_bwd")
-        return d_out, d_table, None
+        return d_out, d_table, None, None
 
 
 def full_sort_cross_entropy(output: torch.Tensor, table: torch.Tensor, target: torch.Tensor,
-                            table_grad: bool = True) -> torch.Tensor:
+                            table_grad: bool = True, state=_DEFAULT_STATE) -> torch.Tensor:
     """mean_b [ logsumexp_n(output_b . table_n) - output_b . table_target(b) ].  `table_grad=False` declares that the
     table's gradient of this loss will not be taken (see _FullSortCEDir): same values, cheaper backward."""
     fn = _FullSortCE if table_grad else _FullSortCEDir
-    return fn.apply(output.contiguous(), table, target).mean()
+    return fn.apply(output.contiguous(), table, target, state).mean()
 
 
 def full_sort_cross_entropy_rows(output: torch.Tensor, table: torch.Tensor, target: torch.Tensor,
-                                 table_grad: bool = True) -> torch.Tensor:
+                                 table_grad: bool = True, state=_DEFAULT_STATE) -> torch.Tensor:
     """Per-row losses `CrossEntropyLoss(reduction='none')(output @ table.T, target)` (acbert4rec.py:201-206)."""
     fn = _FullSortCE if table_grad else _FullSortCEDir
-    return fn.apply(output.contiguous(), table, target)
+    return fn.apply(output.contiguous(), table, target, state)
 
 
 def supported(hidden_size: int) -> bool:

@@ -181,12 +181,24 @@ __global__ void __launch_bounds__(64, (stream_waves<DH, NT>())) acattn_fwd_strea
   // ---- pass 1: scores, spatial calibrator, first-level softmaxes ----------------------------------------------------------
   f4 tS[NT], tM[NT];
   float mx = ACATTN_NEG_INF, my = ACATTN_NEG_INF;
+  // the fragments of tile t + 1 are requested before tile t is worked on: a wave's chain of L2 round trips would
+  // otherwise be as long as its arithmetic
+  f4 kq[KS / 4], kaq[KS / 4];
+  key_frag(P.k, 0, kq);
+  if (ADV) key_frag(P.ka, 0, kaq);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (t < nt) {
       f4 k4[KS / 4], ka4[KS / 4];
-      key_frag(P.k, t, k4);
-      if (ADV) key_frag(P.ka, t, ka4);
+#pragma unroll
+      for (int s4 = 0; s4 < KS / 4; ++s4) {
+        k4[s4] = kq[s4];
+        if (ADV) ka4[s4] = kaq[s4];
+      }
+      if (t + 1 < NT && t + 1 < nt) {
+        key_frag(P.k, t + 1, kq);
+        if (ADV) key_frag(P.ka, t + 1, kaq);
+      }
       // key halves of the affines for key 16 t + c (rank-1 form of layers.py:705-708), then to the lanes of the D layout
       float co = 0.f, cd = 0.f;
       f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS;

@@ -14,7 +14,8 @@ from typing import Optional
 
 import torch
 
-from . import _lib, linear, ops
+from . import _lib, ops
+from .state import state_of
 from .ops import _need_cuda, _ptr, _stream
 
 
@@ -32,7 +33,8 @@ def _problem(idx, table, pos, gamma, beta, eps, p_drop, keep, seed, seed_tensor)
 
 class _EmbedLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, idx, table, pos, gamma, beta, eps, p_drop, keep, seed, seed_tensor, padding_idx):
+    def forward(ctx, idx, table, pos, gamma, beta, eps, p_drop, keep, seed, seed_tensor, padding_idx, state):
+        ctx.state = state
         _need_cuda("item_seq", idx, torch.int64)
         for name, t in (("item_embedding.weight", table), ("LayerNorm.weight", gamma), ("LayerNorm.bias", beta)):
             _need_cuda(name, t)
@@ -58,8 +60,8 @@ class _EmbedLayerNorm(torch.autograd.Function):
     def backward(ctx, dy):
         idx, table, pos, gamma, beta, stats, keep, seed_tensor = ctx.saved_tensors
         eps, p_drop, has_pos, has_keep, seed, has_seed_t, padding_idx = ctx.args
-        if linear._ATTACK_PASS_ONLY:  # none of these parameters is an attack transform (trainer.py:678-684)
-            return (None,) * 11
+        if ctx.state.attack_pass_only:  # none of these parameters is an attack transform (trainer.py:678-684)
+            return (None,) * 12
         lib = _lib.load()
         p = _problem(idx, table, pos if has_pos else None, gamma, beta, eps, p_drop, keep if has_keep else None, seed,
                      seed_tensor if has_seed_t else None)
@@ -80,7 +82,7 @@ class _EmbedLayerNorm(torch.autograd.Function):
         if want_gb:
             gb = ops.sum_rows(gb_part, 0)
             dgamma, dbeta = gb[0], gb[1]
-        return None, d_table, d_pos, dgamma, dbeta, None, None, None, None, None, None
+        return None, d_table, d_pos, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def embed_layer_norm(item_seq: torch.Tensor, item_embedding: torch.nn.Embedding,
@@ -91,10 +93,11 @@ def embed_layer_norm(item_seq: torch.Tensor, item_embedding: torch.nn.Embedding,
     seed = 0
     if p > 0 and keep is None:
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    state = state_of(norm)
     return _EmbedLayerNorm.apply(item_seq.contiguous(), item_embedding.weight,
                                  None if position_embedding is None else position_embedding.weight, norm.weight,
-                                 norm.bias, norm.eps, p, keep, seed, ops.graph_seed_tensor() if keep is None else None,
-                                 item_embedding.padding_idx)
+                                 norm.bias, norm.eps, p, keep, seed, state.seed_tensor if keep is None else None,
+                                 item_embedding.padding_idx, state)
 
 
 def supported(hidden_size: int) -> bool:

@@ -11,7 +11,8 @@ from typing import Optional
 
 import torch
 
-from . import _lib, linear, ops
+from . import _lib, ops
+from .state import state_of
 from .ops import _need_cuda, _ptr, _stream
 
 
@@ -56,7 +57,8 @@ def draw_seed() -> int:
 
 class _DropoutAddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor):
+    def forward(ctx, z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor, state):
+        ctx.state = state
         for name, t in (("z", z), ("residual", res), ("LayerNorm.weight", gamma), ("LayerNorm.bias", beta)):
             _need_cuda(name, t)
         if keep is not None:
@@ -82,7 +84,7 @@ class _DropoutAddLayerNorm(torch.autograd.Function):
         dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
         same = res.numel() == z.numel()
         dres_full = torch.empty_like(z) if ctx.needs_input_grad[1] else None
-        want_gb = (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and not linear._ATTACK_PASS_ONLY
+        want_gb = (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and not ctx.state.attack_pass_only
         part = torch.empty(_lib.LN_BWD_GRID, 2, z.shape[-1], device=z.device, dtype=torch.float32) if want_gb else None
         _lib.check(lib.acattn_dropout_add_layernorm_bwd(C.byref(p), _ptr(dy), _ptr(stats), _ptr(dz), _ptr(dres_full),
                                                         _ptr(part), _stream()), "dropout_add_layernorm_bwd")
@@ -93,7 +95,7 @@ class _DropoutAddLayerNorm(torch.autograd.Function):
         if part is not None:
             gb = ops.sum_rows(part, 0)
             dgamma, dbeta = gb[0], gb[1]
-        return dz, dres, dgamma, dbeta, None, None, None, None, None
+        return dz, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
 def dropout_add_layer_norm(z: torch.Tensor, residual: torch.Tensor, norm: torch.nn.LayerNorm, p_drop: float,
@@ -103,8 +105,9 @@ def dropout_add_layer_norm(z: torch.Tensor, residual: torch.Tensor, norm: torch.
     seed = 0
     if p > 0 and keep is None:
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    state = state_of(norm)
     return _DropoutAddLayerNorm.apply(z.contiguous(), residual.contiguous(), norm.weight, norm.bias, norm.eps, p, keep, seed,
-                                      ops.graph_seed_tensor() if keep is None else None)
+                                      state.seed_tensor if keep is None else None, state)
 
 
 def supported(hidden_size: int) -> bool:

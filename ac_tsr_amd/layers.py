@@ -24,6 +24,7 @@ from . import fused_ln, ops
 from . import tail
 from .linear import projections, skinny_linear
 from .ops import AttentionConfig, ExplicitRandomness, StructuredMask
+from .state import state_of
 
 
 class AttackRMultiHeadAttention(nn.Module):
@@ -185,8 +186,8 @@ class AttackRTransformerLayer(nn.Module):
         want_probs = return_all_attention_prob or return_attention_prob
         ctx_att, ctx_cal, attack_mask, probs = ops.calibrated_attention(
             mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
-            seed_tensor=ops.graph_seed_tensor() if core_rnd is None else None, read_rows=_rows,
-            attack_upstream=_attack_upstream, rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
+            seed_tensor=state_of(self).seed_tensor if core_rnd is None else None, read_rows=_rows,
+            attack_upstream=_attack_upstream, state=state_of(self), rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
         residual = hidden_states
         if _rows is not None:
             index = _rows.unsqueeze(-1).expand(-1, -1, hidden_states.shape[-1])
@@ -220,11 +221,6 @@ class AttackRTransformerLayer(nn.Module):
                     all_attention_prob)
         return attacked_feedforward_output, calibrated_feedforward_output, attack_mask, combined_attention_prob
 
-
-# When False the models run the reference's full schedule: every layer's attacked tail, the last layer's tails on all
-# B*L positions, every input gradient -- the work DESIGN.md section 5 lists as provably without effect.  Same results
-# either way; the switch exists so that both schedules can be measured (bench.py reports both).
-PRUNE_DEAD_WORK = True
 
 
 class AttackRTransformerEncoder(nn.Module):
@@ -260,7 +256,8 @@ class AttackRTransformerEncoder(nn.Module):
             need_attacked = output_all_encoded_layers or layer_idx == len(self.layer) - 1
             outs = layer_module(hidden_states, attention_mask, return_attention_prob, return_all_attention_prob,
                                 _rnd=rnd, _need_attacked=need_attacked,
-                                _attack_upstream=layer_idx > 0 or not PRUNE_DEAD_WORK,
+                                # the first layer owes no input gradient to an attack transform
+                                _attack_upstream=layer_idx > 0 or not state_of(self).prune_dead_work,
                                 _rows=_last_rows if layer_idx == len(self.layer) - 1 else None)
             attacked_hidden_states, calibrated_hidden_states, attack_mask, combined_attention_prob = outs[:4]
             hidden_states = calibrated_hidden_states  # layers.py:1112

@@ -14,51 +14,17 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from .state import DEFAULT as _DEFAULT_STATE, state_of
+
 
 def _sum_rows(x, dim):
     from .ops import sum_rows  # late import: ops imports nothing from here, but keeps module load order simple
     return sum_rows(x, dim)
 
 
-# Set by the trainer while the attacked loss is being differentiated (second backward pass): only the attack
-# transforms accumulate there (recbole/trainer/trainer.py:678-684), so every other layer's weight / bias
-# gradient would be computed and thrown away.  A Python autograd.Function cannot see which of its outputs the
-# engine actually needs, hence this explicit switch.
-_ATTACK_PASS_ONLY = False
-
-
-class attack_pass:
-    """Context manager: inside it, only layers tagged `_acattn_attack = True` produce parameter gradients."""
-
-    def __enter__(self):
-        global _ATTACK_PASS_ONLY
-        self._prev = _ATTACK_PASS_ONLY
-        _ATTACK_PASS_ONLY = True
-
-    def __exit__(self, *exc):
-        global _ATTACK_PASS_ONLY
-        _ATTACK_PASS_ONLY = self._prev
-        return False
-
-
-# The mirror image for pass 1 (calibrated loss, trainer.py:672-677): the attack transforms are frozen there, so their
-# weight / bias gradients would be computed and dropped.
-_CALIBRATED_PASS_ONLY = False
-
-
-class calibrated_pass:
-    """Context manager: inside it, layers tagged `_acattn_attack = True` produce no parameter gradients."""
-
-    def __enter__(self):
-        global _CALIBRATED_PASS_ONLY
-        self._prev = _CALIBRATED_PASS_ONLY
-        _CALIBRATED_PASS_ONLY = True
-
-    def __exit__(self, *exc):
-        global _CALIBRATED_PASS_ONLY
-        _CALIBRATED_PASS_ONLY = self._prev
-        return False
-
+# Which backward pass of the two-pass trainer is running decides which parameter gradients are worth computing
+# (recbole/trainer/trainer.py:672-684); the answer is per-model state captured by every node at forward time:
+# state.StepState.
 
 def _split(m: int) -> int:
     """Number of slabs: the largest divisor of m that is <= 128 and leaves slabs of >= 128 rows."""
@@ -71,10 +37,11 @@ def _split(m: int) -> int:
 
 class _SkinnyLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, is_attack):
+    def forward(ctx, x, weight, bias, is_attack, state):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.is_attack = is_attack
+        ctx.state = state
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -84,14 +51,14 @@ class _SkinnyLinear(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         if ctx.needs_input_grad[0]:
             gx = (g2 @ weight).view_as(x)
-        want_params = (not _CALIBRATED_PASS_ONLY) if ctx.is_attack else (not _ATTACK_PASS_ONLY)
+        want_params = (not ctx.state.calibrated_pass_only) if ctx.is_attack else (not ctx.state.attack_pass_only)
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and want_params
         if ctx.needs_input_grad[1] and want_params:
             from .ops import linear_wgrad
             gw, gb = linear_wgrad(x.reshape(-1, x.shape[-1]), g2, want_b)
         elif want_b:
             gb = _sum_rows(g2, 0)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def skinny_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
@@ -99,7 +66,7 @@ def skinny_linear(x: torch.Tensor, layer: torch.nn.Linear) -> torch.Tensor:
     state-dict tests) take the stock path."""
     if not x.is_cuda or not torch.is_grad_enabled():
         return layer(x)
-    return _SkinnyLinear.apply(x, layer.weight, layer.bias, getattr(layer, "_acattn_attack", False))
+    return _SkinnyLinear.apply(x, layer.weight, layer.bias, getattr(layer, "_acattn_attack", False), state_of(layer))
 
 
 class _Projections(torch.autograd.Function):
@@ -112,13 +79,14 @@ class _Projections(torch.autograd.Function):
     gradients come from acattn_linear_wgrad.  Gradients reach exactly the leaves the six nn.Linear would feed."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg, attack_upstream):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg, attack_upstream, state):
         mq, mk, mv = F.linear(x, wq, bq), F.linear(x, wk, bk), F.linear(x, wv, bv)
         qa, ka = F.linear(mq, waq, baq), F.linear(mk, wak, bak)
         gate = F.linear(mq, wg, bg) if wg is not None else None
         ctx.save_for_backward(x, mq, mk, wq, wk, wv, waq, wak, wg if wg is not None else x.new_empty(0))
         ctx.has_gate = wg is not None
         ctx.attack_upstream = attack_upstream
+        ctx.state = state
         ctx.set_materialize_grads(False)  # unused outputs arrive as None in backward (handled there)
         return mq, mk, mv, qa, ka, gate
 
@@ -137,7 +105,8 @@ class _Projections(torch.autograd.Function):
             return g @ w if total is None else total.addmm_(g, w)
 
         grads = [None] * 12
-        others = not _ATTACK_PASS_ONLY  # pass 2 keeps only the attack transforms (trainer.py:678-684)
+        others = not ctx.state.attack_pass_only  # pass 2 keeps only the attack transforms (trainer.py:678-684)
+        attack = not ctx.state.calibrated_pass_only  # pass 1 has them frozen (trainer.py:672-677)
         # In pass 2 a layer with no attack transform upstream (the first one) owes nobody an input gradient: the only
         # things left to compute are the two attack transforms' own gradients.
         need_dx = ctx.needs_input_grad[0] and (others or ctx.attack_upstream)
@@ -159,15 +128,15 @@ class _Projections(torch.autograd.Function):
         params(1, x2, dmq_t, others)
         params(3, x2, dmk_t, others)
         params(5, x2, dmv, others)
-        params(7, mq2, dqa, not _CALIBRATED_PASS_ONLY)
-        params(9, mk2, dka, not _CALIBRATED_PASS_ONLY)
+        params(7, mq2, dqa, attack)
+        params(9, mk2, dka, attack)
         if ctx.has_gate:
             params(11, mq2, dgate, others)
         if jobs:
             from .ops import linear_wgrad_grouped
             for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs])):
                 grads[slot - 1], grads[slot] = gw, gb
-        return (dx, *grads, None)
+        return (dx, *grads, None, None)
 
 
 def projections(x, query, key, value, attack_query, attack_key, gate=None, attack_upstream=True):
@@ -179,7 +148,7 @@ def projections(x, query, key, value, attack_query, attack_key, gate=None, attac
     return _Projections.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
                               attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
                               gate.weight if gate is not None else None, gate.bias if gate is not None else None,
-                              attack_upstream)
+                              attack_upstream, state_of(query))
 
 
 class _FullSortScores(torch.autograd.Function):
@@ -188,8 +157,9 @@ class _FullSortScores(torch.autograd.Function):
     (100k), the same library pothole as the weight gradients above (242 us -> see profiles/)."""
 
     @staticmethod
-    def forward(ctx, output, table):
+    def forward(ctx, output, table, state):
         ctx.save_for_backward(output, table)
+        ctx.state = state
         return output @ table.t()
 
     @staticmethod
@@ -204,15 +174,15 @@ class _FullSortScores(torch.autograd.Function):
                 g_out = _sum_rows(torch.bmm(g.view(b, s, n // s).transpose(0, 1), table.view(s, n // s, -1)), 0)
             else:
                 g_out = g @ table
-        if ctx.needs_input_grad[1] and not _ATTACK_PASS_ONLY:
+        if ctx.needs_input_grad[1] and not ctx.state.attack_pass_only:
             g_tab = g.t() @ output
-        return g_out, g_tab
+        return g_out, g_tab, None
 
 
-def full_sort_scores(output: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+def full_sort_scores(output: torch.Tensor, table: torch.Tensor, state=_DEFAULT_STATE) -> torch.Tensor:
     if not output.is_cuda or not torch.is_grad_enabled():
         return torch.matmul(output, table.transpose(0, 1))
-    return _FullSortScores.apply(output, table)
+    return _FullSortScores.apply(output, table, state)
 
 
 class _EmbeddingLookup(torch.autograd.Function):
@@ -221,33 +191,34 @@ class _EmbeddingLookup(torch.autograd.Function):
     6.5 MB of atomic traffic).  Row `padding_idx` receives no gradient, like nn.Embedding."""
 
     @staticmethod
-    def forward(ctx, idx, weight, padding_idx):
+    def forward(ctx, idx, weight, padding_idx, state):
         ctx.save_for_backward(idx)
         ctx.shape = weight.shape
         ctx.padding_idx = padding_idx
+        ctx.state = state
         return F.embedding(idx, weight)
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        if _ATTACK_PASS_ONLY:
-            return None, None, None
+        if ctx.state.attack_pass_only:
+            return None, None, None, None
         n, h = ctx.shape
         flat = idx.reshape(-1)
         if ctx.padding_idx is None:
             gw = g.new_zeros(n, h)
             gw.index_add_(0, flat, g.reshape(-1, h))
-            return None, gw, None
+            return None, gw, None, None
         # about half of all lookups hit the padding row: thousands of atomic adds on ONE 256-byte row serialise
         # (measured 300 us).  Their sum is discarded anyway, so they are scattered over 4096 scratch rows instead.
         scratch = 4096
         gw = g.new_zeros(n + scratch, h)
         spread = n + (torch.arange(flat.numel(), device=flat.device) & (scratch - 1))
         gw.index_add_(0, torch.where(flat == ctx.padding_idx, spread, flat), g.reshape(-1, h))
-        return None, gw[:n], None
+        return None, gw[:n], None, None
 
 
 def embedding_lookup(idx: torch.Tensor, emb: torch.nn.Embedding) -> torch.Tensor:
     if not idx.is_cuda or not torch.is_grad_enabled():
         return emb(idx)
-    return _EmbeddingLookup.apply(idx, emb.weight, emb.padding_idx)
+    return _EmbeddingLookup.apply(idx, emb.weight, emb.padding_idx, state_of(emb))

@@ -19,6 +19,7 @@ from .layers import AttackRTransformerEncoder
 from . import ce, fused_embed
 from .linear import embedding_lookup, full_sort_scores
 from .ops import StructuredMask, mask_penalty
+from .state import StepState
 
 
 class ModelType(Enum):
@@ -147,6 +148,8 @@ class ACSASRec(SequentialRecommender):
         else:
             raise NotImplementedError("Make sure 'loss_type' in ['BPR', 'CE']!")
         self.apply(self._init_weights)
+        # pass identity of the two-pass trainer, replay seed counter, schedule switch: per model (state.py)
+        self.step_state = StepState().attach(self)
 
     def _init_weights(self, module):
         """acsasrec.py:74-84: N(0, initializer_range) weights, zero biases, unit LayerNorm."""
@@ -163,7 +166,7 @@ class ACSASRec(SequentialRecommender):
         mask = self.get_structured_mask(item_seq, self.bidirectional)
         # only position item_seq_len - 1 of the last layer is read (acsasrec.py:100-103): the encoder is told, so the
         # last layer's position-wise tail runs on B rows instead of B * L (gather and tail commute)
-        if not layers.PRUNE_DEAD_WORK:  # the reference's full schedule (acsasrec.py:99-103)
+        if not self.step_state.prune_dead_work:  # the reference's full schedule (acsasrec.py:99-103)
             trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
             attacked_output, calibrated_output = trm_output[0][-1]
             return (self.gather_indexes(attacked_output, item_seq_len - 1),
@@ -184,8 +187,9 @@ class ACSASRec(SequentialRecommender):
         if output.is_cuda and ce.supported(self.hidden_size) and torch.is_grad_enabled():
             # fused: the [B, n_items] logits (205 MB at 512 x 100k) are never written
             # the attacked loss is differentiated for the attack transforms only (trainer.py:678-684): no table gradient
-            return ce.full_sort_cross_entropy(output, self.item_embedding.weight, pos_items, table_grad=not attack_loss)
-        logits = full_sort_scores(output, self.item_embedding.weight)
+            return ce.full_sort_cross_entropy(output, self.item_embedding.weight, pos_items, table_grad=not attack_loss,
+                                              state=self.step_state)
+        logits = full_sort_scores(output, self.item_embedding.weight, self.step_state)
         return self.loss_fct(logits, pos_items)
 
     def calculate_loss(self, interaction, _rnds=None, _keep_emb=None):
@@ -280,6 +284,8 @@ class AcBERT4Rec(SequentialRecommender):
         if self.loss_type not in ('BPR', 'CE'):
             raise AssertionError("Make sure 'loss_type' in ['BPR', 'CE']!")
         self.apply(self._init_weights)
+        # pass identity of the two-pass trainer, replay seed counter, schedule switch: per model (state.py)
+        self.step_state = StepState().attach(self)
 
     _init_weights = ACSASRec._init_weights
 
@@ -353,7 +359,7 @@ class AcBERT4Rec(SequentialRecommender):
         of the two outputs, [B,R,H] (see AttackRTransformerLayer.forward)."""
         input_emb = _front_end(self, item_seq, _keep_emb)
         mask = self.get_structured_mask(item_seq, bidirectional=True)
-        if not layers.PRUNE_DEAD_WORK:  # the reference's full schedule, rows picked afterwards (acbert4rec.py:219-225)
+        if not self.step_state.prune_dead_work:  # the reference's full schedule, rows picked afterwards (acbert4rec.py:219-225)
             trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
             attacked_output, calibrated_output = trm_output[0][-1]
             if _rows is not None:
@@ -377,9 +383,11 @@ class AcBERT4Rec(SequentialRecommender):
         table = self.item_embedding.weight[:self.n_items]
         rows = seq_output.reshape(-1, seq_output.size(-1))
         if rows.is_cuda and ce.supported(self.hidden_size) and torch.is_grad_enabled():
-            per_slot = ce.full_sort_cross_entropy_rows(rows, table, pos_items.reshape(-1), table_grad=not attack_loss)
+            per_slot = ce.full_sort_cross_entropy_rows(rows, table, pos_items.reshape(-1), table_grad=not attack_loss,
+                                                       state=self.step_state)
         else:
-            per_slot = nn.functional.cross_entropy(full_sort_scores(rows, table), pos_items.reshape(-1), reduction='none')
+            per_slot = nn.functional.cross_entropy(full_sort_scores(rows, table, self.step_state), pos_items.reshape(-1),
+                                                   reduction='none')
         return torch.sum(per_slot * targets) / torch.sum(targets)
 
     def calculate_loss(self, interaction, _cloze=None, _rnds=None, _keep_emb=None):

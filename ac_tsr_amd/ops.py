@@ -18,7 +18,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from . import linear as linear_mod
+from .state import DEFAULT as _DEFAULT_STATE
 from ._lib import BwdIO, FwdOut, Problem
 
 
@@ -57,19 +57,6 @@ class ExplicitRandomness:
     keep_after: Optional[torch.Tensor] = None
     keep_mask: Optional[torch.Tensor] = None
     keep_before: Optional[torch.Tensor] = None
-
-
-_GRAPH_SEED: Optional[torch.Tensor] = None
-
-
-def set_graph_seed_tensor(t: Optional[torch.Tensor]) -> None:
-    """Device int64[1] step counter that every counter-RNG launch adds to its seed (None = off)."""
-    global _GRAPH_SEED
-    _GRAPH_SEED = t
-
-
-def graph_seed_tensor() -> Optional[torch.Tensor]:
-    return _GRAPH_SEED
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -183,10 +170,11 @@ class _CalibratedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, mask,
                 cfg: AttentionConfig, p_drop: float, rnd, seed: int, want_probs: bool, seed_tensor=None,
-                read_rows=None, attack_upstream=True):
+                read_rows=None, attack_upstream=True, state=_DEFAULT_STATE):
         lib = _lib.load()
         B, L, H = q.shape
         ctx.attack_upstream = attack_upstream
+        ctx.state = state
         ctx.set_materialize_grads(False)  # an output nobody differentiated arrives as None, not as a zero tensor
         ctx.active_qblocks = None
         if read_rows is not None:
@@ -263,11 +251,11 @@ class _CalibratedAttention(torch.autograd.Function):
         # the hint is only valid when the mask cotangent (which reaches every row) is absent
         io.active_qblocks = _ptr(ctx.active_qblocks) if (ctx.active_qblocks is not None and d_M is None) else None
         # pass 2 through a layer with nothing attack-related upstream: only the attack transforms' inputs matter
-        attack_only = linear_mod._ATTACK_PASS_ONLY and not ctx.attack_upstream
+        attack_only = ctx.state.attack_pass_only and not ctx.attack_upstream
         io.attack_only = int(attack_only)
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
         if attack_only:
-            return (None, None, None, dqa, dka) + (None,) * 16
+            return (None, None, None, dqa, dka) + (None,) * 17
         if dgate_part is not None:
             dgate = sum_rows(dgate_part, 1)  # the gate is shared by the heads (layers.py:887 unsqueeze(1))
         tot = sum_rows(part, 0)
@@ -279,18 +267,21 @@ class _CalibratedAttention(torch.autograd.Function):
         g_sc = small[2:3].view_as(scalar) if w_dist is not None else None
         g_rr = small[3:4].view_as(rich_ratio) if rich_ratio is not None else None
         return (dq, dk, dv, dqa, dka, dgate, g_wo, g_bo, g_wd, g_bd, g_sc, g_rr, None, None, None, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfig, *, w_order=None, b_order=None,
                          w_dist=None, b_dist=None, scalar=None, rich_ratio=None, p_drop: float = 0.0,
                          rnd: Optional[ExplicitRandomness] = None, seed: Optional[int] = None,
                          want_probs: bool = False, seed_tensor: Optional[torch.Tensor] = None,
-                         read_rows: Optional[torch.Tensor] = None, attack_upstream: bool = True):
+                         read_rows: Optional[torch.Tensor] = None, attack_upstream: bool = True,
+                         state=_DEFAULT_STATE):
     """Fused core of one AttackRTransformerLayer between the projections and the output dense.
 
     `attack_upstream=False` declares that nothing that produced q, k, v holds attack transforms (first encoder layer):
     in pass 2 of the two-pass trainer the backward then returns only the gradients of qa and ka.
+
+    `state` (state.StepState) tells the backward which pass of the two-pass trainer is running.
 
     `read_rows` ([B, R] int64, optional) promises that the two context outputs are only ever read at those positions
     of each sequence: the backward then skips query blocks that cannot carry a cotangent (a speed hint; results are
@@ -305,7 +296,7 @@ def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfi
     # into the graph, the tensor is what changes between replays (trainer.enable_graph)
     outs = _CalibratedAttention.apply(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar,
                                       rich_ratio, mask, cfg, p_drop, rnd, seed or 0, want_probs, seed_tensor, read_rows,
-                                      attack_upstream)
+                                      attack_upstream, state)
     names = ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")
     probs = {n: t for n, t in zip(names, outs[3:]) if t is not None}
     return outs[0], outs[1], outs[2], probs

@@ -1,0 +1,82 @@
+"""Per-model step state read by the custom autograd nodes.
+
+The two-pass trainer (recbole/trainer/trainer.py:672-686) differentiates two losses over ONE graph: pass 1 with
+the attack transforms frozen, pass 2 with only the attack transforms live.  A Python autograd.Function cannot see
+which of its outputs the engine needs, so the nodes of this package ask "which pass is running?" to skip gradients
+that would be computed and dropped.  That answer, the device-side step counter added to the kernels' random seeds
+under hipGraph replay, and the dead-work switch of DESIGN.md section 5 are state of ONE model being trained by ONE
+trainer: they live in a `StepState` object that the model attaches to its modules and every node captures at
+forward time (`ctx.state`).  Two models / trainers in one process therefore cannot disturb each other, and a module
+used on its own (no model around it) sees `DEFAULT`, which is frozen: every gradient is computed.
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from typing import Optional
+
+import torch
+
+
+class StepState:
+    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "_frozen")
+
+    def __init__(self, frozen: bool = False):
+        object.__setattr__(self, "_frozen", False)
+        self.pass_mode: Optional[str] = None  # None | "calibrated" | "attack"
+        self.seed_tensor: Optional[torch.Tensor] = None  # device int64[1], added to every counter-RNG seed
+        # False = the reference's full schedule: every layer's attacked tail, the last layer's tails on all positions,
+        # every input gradient (same results; bench.py measures both)
+        self.prune_dead_work: bool = True
+        object.__setattr__(self, "_frozen", frozen)
+
+    def __setattr__(self, name, value):
+        if self._frozen:
+            raise AttributeError("state.DEFAULT is read-only: attach a StepState to the model (StepState().attach(model))")
+        object.__setattr__(self, name, value)
+
+    def __deepcopy__(self, memo):
+        new = StepState()
+        new.pass_mode, new.prune_dead_work = self.pass_mode, self.prune_dead_work
+        new.seed_tensor = None if self.seed_tensor is None else self.seed_tensor.clone()
+        memo[id(self)] = new
+        return new
+
+    # pass 2 (attacked loss): only the attack transforms accumulate (trainer.py:678-684)
+    @property
+    def attack_pass_only(self) -> bool:
+        return self.pass_mode == "attack"
+
+    # pass 1 (calibrated loss): the attack transforms are frozen (trainer.py:672-677)
+    @property
+    def calibrated_pass_only(self) -> bool:
+        return self.pass_mode == "calibrated"
+
+    @contextmanager
+    def _pass(self, mode):
+        prev = self.pass_mode
+        self.pass_mode = mode
+        try:
+            yield self
+        finally:
+            self.pass_mode = prev
+
+    def calibrated_pass(self):
+        """Inside: layers tagged `_acattn_attack = True` produce no parameter gradients."""
+        return self._pass("calibrated")
+
+    def attack_pass(self):
+        """Inside: only layers tagged `_acattn_attack = True` produce parameter gradients."""
+        return self._pass("attack")
+
+    def attach(self, module: torch.nn.Module) -> "StepState":
+        for m in module.modules():
+            m.__dict__["_step_state"] = self
+        return self
+
+
+DEFAULT = StepState(frozen=True)
+
+
+def state_of(module) -> StepState:
+    """The StepState a module was attached to, or the frozen default."""
+    return module.__dict__.get("_step_state", DEFAULT) if module is not None else DEFAULT

@@ -14,13 +14,15 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from . import fused_ln, linear, ops
+from . import fused_ln, ops
+from .state import state_of
 
 
 class _LayerTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1, p2, keep1, keep2, seed1, seed2,
-                seed_tensor):
+                seed_tensor, state):
+        ctx.state = state
         c, x = c.contiguous(), x.contiguous()
         k1 = None if keep1 is None else keep1.to(torch.uint8).contiguous()
         k2 = None if keep2 is None else keep2.to(torch.uint8).contiguous()
@@ -42,7 +44,7 @@ class _LayerTail(torch.autograd.Function):
         (c, x, h1, st1, a, h2, act, h3, st2, wd, g1, b1, w1, w2, g2, b2, k1, k2, seed_t) = ctx.saved_tensors
         eps1, eps2, p1, p2, has_k1, has_k2, seed1, seed2, has_seed_t = ctx.args
         k1, k2, seed_t = (k1 if has_k1 else None), (k2 if has_k2 else None), (seed_t if has_seed_t else None)
-        params = not linear._ATTACK_PASS_ONLY  # none of these parameters is an attack transform (trainer.py:678-684)
+        params = not ctx.state.attack_pass_only  # none of these parameters is an attack transform (trainer.py:678-684)
         two = lambda t: t.reshape(-1, t.shape[-1])
         # feed-forward block
         d_h3, d_a, part2 = fused_ln.backward_raw(h3, a, g2, b2, eps2, p2, k2, seed2, seed_t, st2, d_out, want_gb=params)
@@ -60,7 +62,7 @@ class _LayerTail(torch.autograd.Function):
                 [(two(c), two(d_h1), True), (two(a), two(d_h2), True), (two(act), two(d_h3), True)])
             gb = ops.sum_rows(torch.stack((part1, part2)), 1)  # [2 norms, (dgamma, dbeta), H] in one pass
             grads = [gwd, gbd, gb[0, 0], gb[0, 1], gw1, gb1, gw2, gb2, gb[1, 0], gb[1, 1]]
-        return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None)
+        return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None, None)
 
 
 def supported(att, ffn) -> bool:
@@ -77,8 +79,9 @@ def layer_tail(ctx_layer, input_tensor, att, ffn, keep_out=None, keep_ffn=None):
     p2 = ffn.dropout.p if (training or keep_ffn is not None) else 0.0
     seed1 = fused_ln.draw_seed() if (p1 > 0 and keep_out is None) else 0
     seed2 = fused_ln.draw_seed() if (p2 > 0 and keep_ffn is None) else 0
-    seed_t = ops.graph_seed_tensor() if (keep_out is None and keep_ffn is None) else None
+    state = state_of(att)
+    seed_t = state.seed_tensor if (keep_out is None and keep_ffn is None) else None
     return _LayerTail.apply(ctx_layer, input_tensor, att.dense.weight, att.dense.bias, att.LayerNorm.weight,
                             att.LayerNorm.bias, ffn.dense_1.weight, ffn.dense_1.bias, ffn.dense_2.weight,
                             ffn.dense_2.bias, ffn.LayerNorm.weight, ffn.LayerNorm.bias, att.LayerNorm.eps,
-                            ffn.LayerNorm.eps, p1, p2, keep_out, keep_ffn, seed1, seed2, seed_t)
+                            ffn.LayerNorm.eps, p1, p2, keep_out, keep_ffn, seed1, seed2, seed_t, state)

@@ -15,8 +15,7 @@ from typing import Iterable, Optional
 import torch
 from torch import optim
 
-from . import ops
-from .linear import attack_pass, calibrated_pass
+from .state import StepState
 
 
 def is_attack_param(name: str) -> bool:
@@ -35,6 +34,9 @@ class AttackSASRecTrainer:
         self.weight_decay = (config['weight_decay'] or 0.0) if config is not None else 0.0
         self.device = next(model.parameters()).device
         self.grad_sync = grad_sync
+        # the step state the model's autograd nodes read (which backward pass is running, replay seed counter);
+        # owned by the model so that two trainers / models in one process stay independent
+        self.state = getattr(model, 'step_state', None) or StepState().attach(model)
         self.optimizer = self._build_optimizer()
         self._graph = None
         for name, module in model.named_modules():  # lets the linear layers skip discarded gradients in pass 2
@@ -85,10 +87,10 @@ class AttackSASRecTrainer:
         # requires_grad, then walks the WHOLE graph twice (frozen leaves just drop what reaches them).
         # `backward(inputs=...)` accumulates into exactly the same leaves with the same values, and lets
         # autograd skip the branches that only feed frozen leaves (weight-gradient GEMMs, embedding scatter).
-        with calibrated_pass():
+        with self.state.calibrated_pass():
             calibrated_loss.backward(retain_graph=attacked_loss is not None, inputs=self._others)
         if attacked_loss is not None:
-            with attack_pass():
+            with self.state.attack_pass():
                 attacked_loss.backward(inputs=self._attack)
         if with_optimizer:
             if self.grad_sync is not None:
@@ -107,9 +109,15 @@ class AttackSASRecTrainer:
         graph ends after the second backward and the all-reduce + optimizer step stay eager."""
         assert self.device.type == 'cuda'
         assert warmup >= 1, "at least one eager step must precede the capture (it creates the optimizer's state)"
+        for m in self.model.modules():
+            # 'annealing' advances a host-side step counter on every forward (recbole/model/layers.py:890-891) and the
+            # rate travels to the kernel by value: a replayed graph would keep the rate of the capture forever
+            if getattr(m, 'combine_option', None) == 'annealing':
+                raise ValueError("combine_option='annealing' cannot run from a captured graph: the anneal rate is "
+                                 "recomputed on the host for every forward (layers.py:890-891); train it eagerly")
         self._static_in = {k: v.clone() for k, v in example_interaction.items()}
         self._seed_t = torch.zeros(1, dtype=torch.int64, device=self.device)
-        ops.set_graph_seed_tensor(self._seed_t)
+        self.state.seed_tensor = self._seed_t
         self._graph_has_optimizer = self.grad_sync is None
         self.model.train()
         side = torch.cuda.Stream()
@@ -132,6 +140,9 @@ class AttackSASRecTrainer:
         to synchronise).  In graph mode the returned tensors are static buffers overwritten by the next step."""
         if self._graph is None:
             return self._eager_step(interaction, check_nan)
+        if any(interaction[k].shape != buf.shape for k, buf in self._static_in.items()):
+            # e.g. the shorter last batch of an epoch: the captured graph is shape-specific, run this one eagerly
+            return self._eager_step(interaction, check_nan)
         for k, buf in self._static_in.items():
             src = interaction[k]
             if src.data_ptr() != buf.data_ptr():
@@ -149,16 +160,21 @@ class AttackSASRecTrainer:
     def _train_epoch(self, train_data: Iterable, epoch_idx: int = 0, attack: bool = True, calibrate: bool = True):
         assert attack or calibrate
         self.model.train()
-        total_att: Optional[torch.Tensor] = None
-        total_cal: Optional[torch.Tensor] = None
+        # owned accumulators: in graph mode train_step returns static buffers that the next replay overwrites, so the
+        # running sums must never alias them (the reference sums .item() values, trainer.py:664-669; one sync per
+        # epoch here instead of two per batch)
+        total_att = torch.zeros((), device=self.device)
+        total_cal = torch.zeros((), device=self.device)
+        saw_att = False
         for interaction in train_data:
             interaction = {k: v.to(self.device) for k, v in interaction.items()} if isinstance(interaction, dict) \
                 else interaction.to(self.device)
             att, cal = self.train_step(interaction, check_nan=True)
             if att is not None:
-                total_att = att.detach() if total_att is None else total_att + att.detach()
-            total_cal = cal.detach() if total_cal is None else total_cal + cal.detach()
-        return (0 if total_att is None else total_att.item()), (0 if total_cal is None else total_cal.item())
+                total_att += att.detach()
+                saw_att = True
+            total_cal += cal.detach()
+        return (total_att.item() if saw_att else 0), total_cal.item()
 
     @torch.no_grad()
     def evaluate_scores(self, interaction):

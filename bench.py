@@ -261,8 +261,7 @@ def main():
     # skipped): reported next to `value` so that both can be judged.  Single GPU only, short, after the timed region.
     full_ms = None
     if world == 1 and not a.no_full_schedule:
-        from ac_tsr_amd import layers as _layers
-        _layers.PRUNE_DEAD_WORK = False
+        model.step_state.prune_dead_work = False
         try:
             full_trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model)
             if not a.no_graph:
@@ -277,7 +276,7 @@ def main():
             torch.cuda.synchronize()
             full_ms = (time.perf_counter() - t1) / n_full * 1e3
         finally:
-            _layers.PRUNE_DEAD_WORK = True
+            model.step_state.prune_dead_work = True
 
     if rank == 0:
         res = {

@@ -99,11 +99,12 @@ def _rnds_for(c: Case, n_layers, train):
 
 
 @pytest.mark.parametrize("name", ["model_eval", "model_eval_stress", "model_train"])
-def test_two_pass_trainer_gradients_match_reference(name):
+def test_two_pass_trainer_gradients_match_reference(name, prune_dead_work=True):
     """calculate_loss + the trainer's two backward passes: losses and every parameter gradient against
     the tensors the genuine reference produced (tests/golden/model_*.npz)."""
     c = Case(name)
     cfg, model = _build_model(c)
+    model.step_state.prune_dead_work = prune_dead_work
     train = bool(int(c.raw["meta.train"]))
     model.train(train)
     batch = {k: v.to(DEV) for k, v in c.batch().items()}
@@ -204,7 +205,6 @@ def test_graph_mode_matches_eager_and_redraws_randomness():
     for _ in range(40):
         att, cal = trainer.train_step(batch)
     assert cal.item() < first - 0.3, (first, cal.item())
-    A.ops.set_graph_seed_tensor(None)
 
 
 @pytest.mark.parametrize("causal", [True, False])
@@ -248,12 +248,10 @@ def test_fast_training_backward_equals_general_backward(causal, p_drop, shape):
 
 
 @pytest.mark.parametrize("name", ["model_eval", "model_train"])
-def test_reference_schedule_switch_gives_the_same_gradients(name, monkeypatch):
-    """layers.PRUNE_DEAD_WORK = False (every tail on all positions, every layer's attacked branch, every input
-    gradient: the reference's schedule) against the same golden vectors the default schedule is checked with."""
-    from ac_tsr_amd import layers
-    monkeypatch.setattr(layers, "PRUNE_DEAD_WORK", False)
-    test_two_pass_trainer_gradients_match_reference(name)
+def test_reference_schedule_switch_gives_the_same_gradients(name):
+    """model.step_state.prune_dead_work = False (every tail on all positions, every layer's attacked branch, every
+    input gradient: the reference's schedule) against the same golden vectors the default schedule is checked with."""
+    test_two_pass_trainer_gradients_match_reference(name, prune_dead_work=False)
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -282,6 +280,48 @@ def test_data_parallel_code_path_matches_plain_trainer(graph):
             trainer.train_step(batch)
         torch.cuda.synchronize()
         states.append({k: v.detach().clone() for k, v in model.state_dict().items()})
-        A.ops.set_graph_seed_tensor(None)
     for k in states[0]:
         assert (states[0][k] - states[1][k]).abs().max() <= 1e-6 * max(1.0, states[0][k].abs().max().item()), k
+
+
+def test_two_trainers_in_one_process_are_independent():
+    """The pass identity and the replay seed counter are per-model state (state.StepState): a second model being
+    trained in the same process, interleaved step by step and even from inside the other model's pass context, does
+    not change what the first one learns."""
+    cfgd = dict(n_layers=2, n_heads=2, hidden_size=64, inner_size=256, hidden_dropout_prob=0.1, attn_dropout_prob=0.2,
+                hidden_act='gelu', layer_norm_eps=1e-12, initializer_range=0.02, loss_type='CE', combine_option='gate',
+                two_level=True, use_order=True, use_distance=True, mask_loss_weight=0.03)
+    g = torch.Generator().manual_seed(1)
+    B, L, N = 32, 50, 500
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.randint(1, N, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    batch = {"item_id_list": ids.to(DEV), "item_length": lens.to(DEV), "item_id": ids[torch.arange(B), lens - 1].to(DEV)}
+
+    def run(with_intruder):
+        torch.manual_seed(3)
+        model = A.ACSASRec(A.DictConfig(cfgd), A.ItemCount(N)).to(DEV)
+        trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), model)
+        other = A.ACSASRec(A.DictConfig(cfgd), A.ItemCount(N)).to(DEV)
+        other_trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), other)
+        assert model.step_state is not other.step_state and trainer.state is model.step_state
+        for step in range(3):
+            torch.manual_seed(100 + step)
+            if with_intruder:
+                with other.step_state.attack_pass():  # somebody else's pass context must not leak into `model`
+                    trainer.train_step(batch)
+                cpu_rng = torch.get_rng_state()
+                other_trainer.train_step(batch)
+                torch.set_rng_state(cpu_rng)
+            else:
+                trainer.train_step(batch)
+        torch.cuda.synchronize()
+        assert model.step_state.pass_mode is None
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    alone, together = run(False), run(True)
+    for k in alone:  # (float atomics in the embedding scatter: equal to rounding, not bit for bit)
+        assert (alone[k] - together[k]).abs().max() <= 1e-6 * max(1.0, alone[k].abs().max().item()), k
+    from ac_tsr_amd import state
+    with pytest.raises(AttributeError):  # the default state of stand-alone modules is read-only
+        state.DEFAULT.pass_mode = "attack"
+
