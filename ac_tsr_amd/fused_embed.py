@@ -90,10 +90,8 @@ def embed_layer_norm(item_seq: torch.Tensor, item_embedding: torch.nn.Embedding,
                      training: bool, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dropout(norm(item_embedding(item_seq) + position_embedding(arange(L))), p_drop, training) -> [B, L, H]."""
     p = p_drop if (training or keep is not None) else 0.0
-    seed = 0
-    if p > 0 and keep is None:
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
     state = state_of(norm)
+    seed = state.draw_seed() if (p > 0 and keep is None) else 0
     return _EmbedLayerNorm.apply(item_seq.contiguous(), item_embedding.weight,
                                  None if position_embedding is None else position_embedding.weight, norm.weight,
                                  norm.bias, norm.eps, p, keep, seed, state.seed_tensor if keep is None else None,

@@ -50,11 +50,6 @@ def backward_raw(z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor, stat
     return dz, dres, part
 
 
-def draw_seed() -> int:
-    """One 63-bit seed for the library's counter RNG from torch's CPU generator (reproducible under manual_seed)."""
-    return int(torch.empty((), dtype=torch.int64).random_().item())
-
-
 class _DropoutAddLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, res, gamma, beta, eps, p_drop, keep, seed, seed_tensor, state):
@@ -102,10 +97,8 @@ def dropout_add_layer_norm(z: torch.Tensor, residual: torch.Tensor, norm: torch.
                            training: bool, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
     """norm(dropout(z, p_drop, training) + residual).  `keep` (0/1, shape of z) replaces the random draw."""
     p = p_drop if (training or keep is not None) else 0.0
-    seed = 0
-    if p > 0 and keep is None:
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
     state = state_of(norm)
+    seed = state.draw_seed() if (p > 0 and keep is None) else 0
     return _DropoutAddLayerNorm.apply(z.contiguous(), residual.contiguous(), norm.weight, norm.bias, norm.eps, p, keep, seed,
                                       state.seed_tensor if keep is None else None, state)
 

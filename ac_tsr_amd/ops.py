@@ -290,8 +290,7 @@ def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfi
     Returns (ctx_attacked [B,L,H] | None, ctx_calibrated [B,L,H], M [B,h,L,L] | None, probs dict).
     """
     if rnd is None and seed is None:
-        # one 63-bit seed per call from torch's CPU generator: reproducible under torch.manual_seed, no device sync
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        seed = state.draw_seed()  # one 63-bit seed per call, salted per data-parallel rank
     # seed_tensor (device int64[1]) is added to `seed` inside the kernels: under hipGraph capture `seed` is frozen
     # into the graph, the tensor is what changes between replays (trainer.enable_graph)
     outs = _CalibratedAttention.apply(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar,

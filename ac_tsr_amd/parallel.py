@@ -1,12 +1,25 @@
 """Batch data-parallelism: one process per MI355X, RCCL (torch.distributed "nccl" on ROCm) over xGMI.
 
 The reference has no distributed code.  Sequences are independent through the whole forward, so the
-batch dimension is split across ranks with replicated parameters and ONE exchange step per
-optimizer step: an average all-reduce of all gradients after the second backward pass
-(recbole/trainer/trainer.py:684 -> :687).  All parameter gradients live in one flat fp32 buffer
-(`.grad` tensors are views into it), so the exchange is a single large collective instead of ~60
-small ones: on MI355X's point-to-point xGMI fabric few, large messages are what keeps the 7 links
-busy; the item-embedding gradient ([n_items, H], dense because CE scores every item) dominates it.
+batch dimension is split across ranks with replicated parameters and the gradients are averaged
+between the backward passes and the optimizer step (recbole/trainer/trainer.py:684 -> :687).  All
+parameter gradients live in one flat fp32 buffer (`.grad` tensors are views into it), so the exchange
+is a few large collectives instead of ~60 small ones: on MI355X's point-to-point xGMI fabric few, large
+messages are what keeps the 7 links busy; the item-embedding gradient ([n_items, H], dense because CE
+scores every item) dominates it.
+
+Overlap.  Under the two-pass protocol every parameter that is not an attack transform has its FINAL
+gradient when pass 1 (calibrated loss) ends: pass 2 only reaches the attack transforms
+(trainer.py:678-684).  `reduce_early()` therefore starts the all-reduce of that part (item table
+included: 99.9 % of the bytes) right after pass 1, on the communication stream, and pass 2 runs under
+it; `all_reduce()` after pass 2 sends the attack transforms' 66 KB and waits for both.
+
+Not identical to one process on the global batch in ONE term: the attacked loss carries
+`torch.norm(1 - M)` over the whole (local) batch (acsasrec.py:131-137), and a norm is not additive.
+Averaging per-rank gradients weights the mask penalty of the attack transforms by 1/sqrt(N) relative
+to a single process seeing all N shards (the cross-entropy terms are exact means).  This is the
+DDP-conventional "per-rank penalty" (SURVEY.md section 8e); every other gradient equals the
+single-process one.
 
 Works with backend "gloo" on CPU tensors as well (world_size-2 tests run without a GPU).
 """
@@ -59,8 +72,15 @@ class GradSynchronizer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None,
-                 accumulate_in_place: bool = False):
-        self.params: List[torch.nn.Parameter] = [p for p in params]
+                 accumulate_in_place: bool = False, late: Iterable[torch.nn.Parameter] = ()):
+        """`late`: the parameters whose gradient is only complete after the LAST backward pass (the attack transforms
+        under the two-pass trainer).  They sit at the end of the flat buffer; everything in front of them can be
+        reduced early (`reduce_early`)."""
+        late_ids = {id(p) for p in late}
+        every = [p for p in params]
+        self.params: List[torch.nn.Parameter] = [p for p in every if id(p) not in late_ids] + \
+                                                [p for p in every if id(p) in late_ids]
+        self.n_early = sum(1 for p in every if id(p) not in late_ids) if late_ids else 0
         assert self.params, "no parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
@@ -75,10 +95,22 @@ class GradSynchronizer:
         if self.in_place:
             self.attach()
         per = max(1, bucket_bytes // self.flat.element_size())
-        self.buckets = [self.flat[s:min(s + per, total)] for s in range(0, total, per)]
+        # buckets never straddle the early / late boundary
+        self.early_numel = sum(p.numel() for p in self.params[:self.n_early])
+        self.early_buckets = [self.flat[s:min(s + per, self.early_numel)] for s in range(0, self.early_numel, per)]
+        self.late_buckets = [self.flat[s:min(s + per, total)] for s in range(self.early_numel, total, per)]
+        self.buckets = self.early_buckets + self.late_buckets
+        self._early_works = None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
+
+    @classmethod
+    def for_two_pass_model(cls, model: torch.nn.Module, **kw) -> "GradSynchronizer":
+        """Synchronizer for a model trained by AttackSASRecTrainer: the attack transforms (selected by name like the
+        reference does, recbole/trainer/trainer.py:672-683) are the `late` parameters."""
+        from .trainer import is_attack_param
+        return cls(model.parameters(), late=[p for n, p in model.named_parameters() if is_attack_param(n)], **kw)
 
     def attach(self) -> None:
         """Make every parameter's .grad the corresponding view of the flat buffer."""
@@ -94,10 +126,12 @@ class GradSynchronizer:
             for p in self.params:
                 p.grad = None
 
-    def pack(self) -> None:
-        """Gather the parameters' gradients into the flat buffer (no-op for gradients that already live there)."""
+    def pack(self, part: str = "all") -> None:
+        """Gather the parameters' gradients into the flat buffer (no-op for gradients that already live there).
+        part: "all", "early" (everything but the `late` parameters) or "late"."""
+        lo, hi = {"all": (0, len(self.params)), "early": (0, self.n_early), "late": (self.n_early, len(self.params))}[part]
         src, dst = [], []
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             g = p.grad
             if g is None:
                 v.zero_()
@@ -107,18 +141,36 @@ class GradSynchronizer:
         if dst:
             torch._foreach_copy_(dst, src)
 
-    def all_reduce(self) -> None:
-        """After this call every parameter's .grad is a view of the flat buffer holding the rank-averaged gradient."""
-        if not self.in_place:
-            self.pack()
-            self.attach()
-        if self.world <= 1:
-            return
+    def _start(self, buckets):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        works = [dist.all_reduce(b, op=op, group=self.group, async_op=True) for b in self.buckets]
+        return [dist.all_reduce(b, op=op, group=self.group, async_op=True) for b in buckets]
+
+    def reduce_early(self, packed: bool = False) -> None:
+        """Call between the backward passes: starts the all-reduce of every gradient that is already final (all but
+        the `late` parameters).  The collective is enqueued behind the work issued so far and runs on the
+        communication stream while the caller keeps launching the last backward pass.  `packed=True`: the early part
+        of the flat buffer was already filled (a captured graph ended with pack("early"))."""
+        if self.n_early == 0:
+            return
+        if not self.in_place and not packed:
+            self.pack("early")
+        self._early_works = self._start(self.early_buckets) if self.world > 1 else []
+
+    def all_reduce(self, packed: bool = False) -> None:
+        """After this call every parameter's .grad is a view of the flat buffer holding the rank-averaged gradient.
+        Reduces what `reduce_early` has not already sent and waits for both."""
+        early_done = self._early_works is not None
+        if not self.in_place:
+            if not packed:
+                self.pack("late" if early_done else "all")
+            self.attach()
+        works = self._early_works or []
+        self._early_works = None
+        if self.world > 1:
+            works = works + self._start(self.late_buckets if early_done else self.buckets)
         for w in works:
             w.wait()
-        if not self._avg:
+        if self.world > 1 and not self._avg:
             self.flat.div_(self.world)
 
 

@@ -18,7 +18,7 @@ import torch
 
 
 class StepState:
-    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "_frozen")
+    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "_frozen")
 
     def __init__(self, frozen: bool = False):
         object.__setattr__(self, "_frozen", False)
@@ -27,6 +27,9 @@ class StepState:
         # False = the reference's full schedule: every layer's attacked tail, the last layer's tails on all positions,
         # every input gradient (same results; bench.py measures both)
         self.prune_dead_work: bool = True
+        # XORed into every kernel seed drawn for this model: data-parallel ranks seed torch's CPU generator alike, the
+        # salt (set from the rank by the trainer) keeps row b of every shard from drawing the same noise and dropout
+        self.seed_salt: int = 0
         object.__setattr__(self, "_frozen", frozen)
 
     def __setattr__(self, name, value):
@@ -36,7 +39,7 @@ class StepState:
 
     def __deepcopy__(self, memo):
         new = StepState()
-        new.pass_mode, new.prune_dead_work = self.pass_mode, self.prune_dead_work
+        new.pass_mode, new.prune_dead_work, new.seed_salt = self.pass_mode, self.prune_dead_work, self.seed_salt
         new.seed_tensor = None if self.seed_tensor is None else self.seed_tensor.clone()
         memo[id(self)] = new
         return new
@@ -67,6 +70,11 @@ class StepState:
     def attack_pass(self):
         """Inside: only layers tagged `_acattn_attack = True` produce parameter gradients."""
         return self._pass("attack")
+
+    def draw_seed(self) -> int:
+        """One 63-bit seed for the library's counter RNG from torch's CPU generator (reproducible under
+        torch.manual_seed, no device sync), salted per rank."""
+        return (int(torch.empty((), dtype=torch.int64).random_().item()) ^ self.seed_salt) & 0x7FFFFFFFFFFFFFFF
 
     def attach(self, module: torch.nn.Module) -> "StepState":
         for m in module.modules():

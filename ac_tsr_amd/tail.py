@@ -77,9 +77,9 @@ def layer_tail(ctx_layer, input_tensor, att, ffn, keep_out=None, keep_ffn=None):
     training = att.training
     p1 = att.out_dropout.p if (training or keep_out is not None) else 0.0
     p2 = ffn.dropout.p if (training or keep_ffn is not None) else 0.0
-    seed1 = fused_ln.draw_seed() if (p1 > 0 and keep_out is None) else 0
-    seed2 = fused_ln.draw_seed() if (p2 > 0 and keep_ffn is None) else 0
     state = state_of(att)
+    seed1 = state.draw_seed() if (p1 > 0 and keep_out is None) else 0
+    seed2 = state.draw_seed() if (p2 > 0 and keep_ffn is None) else 0
     seed_t = state.seed_tensor if (keep_out is None and keep_ffn is None) else None
     return _LayerTail.apply(ctx_layer, input_tensor, att.dense.weight, att.dense.bias, att.LayerNorm.weight,
                             att.LayerNorm.bias, ffn.dense_1.weight, ffn.dense_1.bias, ffn.dense_2.weight,

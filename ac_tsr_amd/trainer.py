@@ -34,6 +34,7 @@ class AttackSASRecTrainer:
         self.weight_decay = (config['weight_decay'] or 0.0) if config is not None else 0.0
         self.device = next(model.parameters()).device
         self.grad_sync = grad_sync
+        self._graph2 = None
         # the step state the model's autograd nodes read (which backward pass is running, replay seed counter);
         # owned by the model so that two trainers / models in one process stay independent
         self.state = getattr(model, 'step_state', None) or StepState().attach(model)
@@ -44,6 +45,10 @@ class AttackSASRecTrainer:
                 module._acattn_attack = is_attack_param(name)
         self._attack = [p for n, p in model.named_parameters() if is_attack_param(n)]
         self._others = [p for n, p in model.named_parameters() if not is_attack_param(n)]
+        if grad_sync is not None:
+            import torch.distributed as dist
+            if dist.is_initialized():  # ranks seed torch's generator alike: keep their in-kernel draws apart
+                self.state.seed_salt = (dist.get_rank(grad_sync.group) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
 
     def _build_optimizer(self):
         params = self.model.parameters()
@@ -68,8 +73,8 @@ class AttackSASRecTrainer:
         if torch.isnan(loss):
             raise ValueError('Training loss is nan')  # trainer.py:763-765
 
-    def _eager_step(self, interaction, check_nan: bool = False, with_optimizer: bool = True):
-        """One batch of trainer.py:660-687."""
+    def _pass_one(self, interaction, check_nan: bool = False):
+        """Forward + backward pass 1 of one batch (trainer.py:660-677).  Returns the two losses."""
         if self._seed_t is not None:
             self._seed_t += 1  # fresh in-kernel randomness on every (replayed) step
         if self.grad_sync is not None:
@@ -89,24 +94,36 @@ class AttackSASRecTrainer:
         # autograd skip the branches that only feed frozen leaves (weight-gradient GEMMs, embedding scatter).
         with self.state.calibrated_pass():
             calibrated_loss.backward(retain_graph=attacked_loss is not None, inputs=self._others)
+        return attacked_loss, calibrated_loss
+
+    def _pass_two(self, attacked_loss):
+        """Backward pass 2 (trainer.py:678-684): only the attack transforms accumulate."""
         if attacked_loss is not None:
             with self.state.attack_pass():
                 attacked_loss.backward(inputs=self._attack)
-        if with_optimizer:
-            if self.grad_sync is not None:
-                self.grad_sync.all_reduce()
-            self.optimizer.step()
-        elif self.grad_sync is not None:
-            self.grad_sync.pack()  # captured with the step; the collective and the optimizer stay outside the graph
+
+    def _eager_step(self, interaction, check_nan: bool = False):
+        """One batch of trainer.py:660-687.  With a gradient synchronizer the all-reduce of everything but the attack
+        transforms (the item table: 99.9 % of the bytes) starts between the passes and pass 2 runs under it."""
+        attacked_loss, calibrated_loss = self._pass_one(interaction, check_nan)
+        if self.grad_sync is not None:
+            self.grad_sync.reduce_early()
+        self._pass_two(attacked_loss)
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce()
+        self.optimizer.step()
         return attacked_loss, calibrated_loss
 
     _seed_t = None
 
     def enable_graph(self, example_interaction, warmup: int = 3):
-        """Capture the training step into a hipGraph (about 600 short kernels per step: eager launches are
-        host-bound).  Inputs are copied into static buffers before each replay; the in-kernel RNG adds a device-side
-        step counter to its seeds so every replay draws fresh noise / dropout.  With a gradient synchronizer the
-        graph ends after the second backward and the all-reduce + optimizer step stay eager."""
+        """Capture the training step into hipGraphs (about 350 short kernels per step: eager launches are host-bound).
+        Inputs are copied into static buffers before each replay; the in-kernel RNG adds a device-side step counter to
+        its seeds so every replay draws fresh noise / dropout.  Without a gradient synchronizer the whole step incl.
+        the optimizer is ONE graph.  With one, the step is TWO graphs sharing a memory pool -- forward + pass 1 +
+        packing of the early gradients, then pass 2 + packing of the attack transforms' -- and the collectives and
+        the optimizer step are issued eagerly: the early all-reduce between the two replays (it overlaps pass 2), the
+        rest after."""
         assert self.device.type == 'cuda'
         assert warmup >= 1, "at least one eager step must precede the capture (it creates the optimizer's state)"
         for m in self.model.modules():
@@ -118,7 +135,6 @@ class AttackSASRecTrainer:
         self._static_in = {k: v.clone() for k, v in example_interaction.items()}
         self._seed_t = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.state.seed_tensor = self._seed_t
-        self._graph_has_optimizer = self.grad_sync is None
         self.model.train()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -128,11 +144,28 @@ class AttackSASRecTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            outs = self._eager_step(self._static_in, with_optimizer=self._graph_has_optimizer)
-        self._graph, self._static_out = graph, outs
-        if self.grad_sync is not None:
+        self._graph2 = None
+        if self.grad_sync is None:
+            with torch.cuda.graph(graph):
+                outs = self._pass_one(self._static_in)
+                self._pass_two(outs[0])
+                self.optimizer.step()
+        else:
+            if self.grad_sync.n_early:
+                with torch.cuda.graph(graph):
+                    outs = self._pass_one(self._static_in)
+                    self.grad_sync.pack("early")
+                self._graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph2, pool=graph.pool()):  # pass 2 walks the autograd graph of pass 1
+                    self._pass_two(outs[0])
+                    self.grad_sync.pack("late")
+            else:  # a synchronizer that was not told which parameters finish late: one graph, one exchange at the end
+                with torch.cuda.graph(graph):
+                    outs = self._pass_one(self._static_in)
+                    self._pass_two(outs[0])
+                    self.grad_sync.pack("all")
             self.grad_sync.attach()  # from now on .grad are the flat views the captured pack() fills on every replay
+        self._graph, self._static_out = graph, outs
         return self
 
     def train_step(self, interaction, check_nan: bool = False):
@@ -148,8 +181,11 @@ class AttackSASRecTrainer:
             if src.data_ptr() != buf.data_ptr():
                 buf.copy_(src, non_blocking=True)
         self._graph.replay()
-        if not self._graph_has_optimizer:
-            self.grad_sync.all_reduce()
+        if self.grad_sync is not None:
+            if self._graph2 is not None:
+                self.grad_sync.reduce_early(packed=True)  # on the communication stream, under the replay of pass 2
+                self._graph2.replay()
+            self.grad_sync.all_reduce(packed=True)
             self.optimizer.step()
         if check_nan:
             for t in self._static_out:

@@ -225,7 +225,7 @@ def main():
     torch.manual_seed(42)  # config/*.yaml seed: 42 -- identical initial parameters on every rank
     model = A.ACSASRec(A.DictConfig(model_config(a)), A.ItemCount(a.items)).to(device)
     parallel.broadcast_parameters(model)
-    sync = parallel.GradSynchronizer(model.parameters()) if (world > 1 or a.force_grad_sync) else None
+    sync = parallel.GradSynchronizer.for_two_pass_model(model) if (world > 1 or a.force_grad_sync) else None
     trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model, grad_sync=sync)
     model.train()
     gen = torch.Generator().manual_seed(1000 + rank)

@@ -254,8 +254,9 @@ def test_reference_schedule_switch_gives_the_same_gradients(name):
     test_two_pass_trainer_gradients_match_reference(name, prune_dead_work=False)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("graph", [False, True])
-def test_data_parallel_code_path_matches_plain_trainer(graph):
+def test_data_parallel_code_path_matches_plain_trainer(graph, split):
     """The N > 1 code path on one GPU (GradSynchronizer: store-then-pack gradients, optimizer fed from the flat buffer,
     graph without the optimizer) updates the parameters exactly like the plain trainer given the same random state."""
     from ac_tsr_amd import parallel
@@ -271,7 +272,9 @@ def test_data_parallel_code_path_matches_plain_trainer(graph):
     for use_sync in (False, True):
         torch.manual_seed(3)
         model = A.ACSASRec(A.DictConfig(cfgd), A.ItemCount(N)).to(DEV)
-        sync = parallel.GradSynchronizer(model.parameters()) if use_sync else None
+        sync = None
+        if use_sync:  # with and without the early / late split (one graph or two)
+            sync = parallel.GradSynchronizer.for_two_pass_model(model) if split else parallel.GradSynchronizer(model.parameters())
         trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), model, grad_sync=sync)
         torch.manual_seed(5)  # the in-kernel RNG seeds are drawn from torch's CPU generator
         if graph:

@@ -156,3 +156,77 @@ def test_two_pass_trainer_protocol_on_cpu_module():
         assert torch.allclose(p.grad, g, atol=1e-6)
     for p, g in zip(m.body.parameters(), g_cal):
         assert torch.allclose(p.grad, g, atol=1e-6)
+
+
+class _TwoPassToy(torch.nn.Module):
+    """A CPU stand-in with the trainer-facing surface of the models: `calculate_loss` returns (attacked, calibrated),
+    and the attack transforms are found by name (recbole/trainer/trainer.py:672-683)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.item_embedding = torch.nn.Embedding(40, 8)
+        self.body = torch.nn.Linear(8, 8)
+        self.attack_query_transform = torch.nn.Linear(8, 8)
+        self.attack_key_transform = torch.nn.Linear(8, 8)
+
+    def calculate_loss(self, batch):
+        x, y = batch
+        h = torch.tanh(self.body(self.item_embedding(x).mean(1)))
+        a = self.attack_query_transform(h) * torch.sigmoid(self.attack_key_transform(h))
+        logits = (h + 0.1 * a) @ self.item_embedding.weight.t()
+        calibrated = torch.nn.functional.cross_entropy(logits, y)
+        attacked = -torch.nn.functional.cross_entropy((h + a) @ self.item_embedding.weight.t(), y)
+        return attacked, calibrated
+
+
+def _toy_batch():
+    g = torch.Generator().manual_seed(4)
+    return torch.randint(0, 40, (16, 6), generator=g), torch.randint(0, 40, (16,), generator=g)
+
+
+def _trainer_worker(rank, world, port, out):
+    import ac_tsr_amd as A
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed("gloo")
+    model = _TwoPassToy()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(0.5)
+    parallel.broadcast_parameters(model, src=0)
+    sync = parallel.GradSynchronizer.for_two_pass_model(model, bucket_bytes=512)
+    assert sync.n_early == 3 and len(sync.early_buckets) > 1 and len(sync.late_buckets) >= 1
+    # the attack transforms sit at the end of the flat buffer, everything else in front
+    assert all(any(p is q for q in model.attack_query_transform.parameters()) or
+               any(p is q for q in model.attack_key_transform.parameters()) for p in sync.params[sync.n_early:])
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner="adam", learning_rate=1e-2), model, grad_sync=sync)
+    assert (trainer.state.seed_salt != 0) == (rank != 0)  # ranks draw different in-kernel seeds
+    x, y = _toy_batch()
+    sl = parallel.shard_batch(x.shape[0], rank, world)
+    for _ in range(3):
+        trainer.train_step((x[sl], y[sl]))
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out, f"trainer_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_pass_trainer_with_synchronizer_on_two_ranks(tmp_path):
+    """AttackSASRecTrainer + GradSynchronizer together over gloo, world size 2: early reduce between the passes, late
+    reduce after them, one Adam step -- replicas stay identical and equal one process on the whole batch (both
+    losses are means over equal shards, so the averaged gradients are the full-batch gradients)."""
+    import ac_tsr_amd as A
+    port = _free_port()
+    mp.spawn(_trainer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s0 = torch.load(tmp_path / "trainer_rank0.pt")
+    s1 = torch.load(tmp_path / "trainer_rank1.pt")
+    model = _TwoPassToy()
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner="adam", learning_rate=1e-2), model)
+    for _ in range(3):
+        trainer.train_step(_toy_batch())
+    ref = model.state_dict()
+    for k in ref:
+        assert torch.equal(s0[k], s1[k]), k
+        assert (s0[k] - ref[k]).abs().max() <= 1e-5, k
+
