@@ -15,13 +15,14 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
 RICH = {"none": 0, "fixed": 1, "trainable": 2}
 RNG_EXPLICIT, RNG_COUNTER = 0, 1
 FWD_AUTO, FWD_STREAM, FWD_STAGED, FWD_GENERAL = 0, 1, 2, 3
+BWD_AUTO, BWD_STREAM, BWD_ROW = 0, 1, 2
 
 _f = C.c_void_p  # every device pointer travels as an integer address
 
@@ -52,7 +53,7 @@ class BwdIO(C.Structure):
         ("d_ctx_attacked", _f), ("d_ctx_calibrated", _f), ("d_attack_mask", _f),
         ("dq", _f), ("dk", _f), ("dv", _f), ("dqa", _f), ("dka", _f), ("dgate_logits", _f),
         ("dw_order_part", _f), ("dw_dist_part", _f), ("dsmall_part", _f), ("part_stride", C.c_int32),
-        ("active_qblocks", _f), ("attack_only", C.c_int32),
+        ("active_qblocks", _f), ("attack_only", C.c_int32), ("workspace", _f),
     ]
 
 
@@ -102,6 +103,8 @@ SYMBOLS = {
                                                C.c_int32, C.c_int64, _f, C.c_void_p]),
     "acattn_linear_wgrad": (C.c_int, [_f, _f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
     "acattn_select_forward_kernel": (C.c_int, [C.c_int]),
+    "acattn_select_backward_kernel": (C.c_int, [C.c_int]),
+    "acattn_calibrated_attention_bwd_workspace_bytes": (C.c_int64, [C.POINTER(Problem)]),
     "acattn_rng_materialize": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_float, _f, _f, _f, _f,
                                          C.c_void_p]),
 }

@@ -66,6 +66,8 @@ int acattn_abi_version(void) { return ACATTN_ABI_VERSION; }
 
 int acattn_select_forward_kernel(int which) { return acattn_fwd_kernel_choice(which); }
 
+int acattn_select_backward_kernel(int which) { return acattn_bwd_kernel_choice(which); }
+
 const char* acattn_last_error(void) { return g_err; }
 
 int64_t acattn_fwd_algorithmic_bytes(const acattn_problem* p) {
@@ -101,6 +103,11 @@ int acattn_calibrated_attention_bwd(const acattn_problem* p, const acattn_bwd_io
   const int rc = acattn_launch_bwd(*p, *io, (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;
+}
+
+int64_t acattn_calibrated_attention_bwd_workspace_bytes(const acattn_problem* p) {
+  if (!p || p->B < 1 || p->L < 1 || p->n_heads < 1) return -1;
+  return acattn_bwd_stream_ws_bytes(*p);
 }
 
 int acattn_rng_materialize(int32_t B, int32_t n_heads, int32_t L, uint64_t seed, float p_drop, float* noise,

@@ -22,6 +22,8 @@
 //   v = P exp(1 - M) + m           A_c = softmax(v)
 //   A_g = combine(P, A_c)          A_w = softmax(A_g + m)
 //   ctx_a = A_p V, ctx_c = A_w V   (recbole/model/layers.py:695-740, 661-672, 917-925, 677-680)
+#include <stdlib.h>
+
 #include "acattn_common.h"
 
 namespace {
@@ -789,9 +791,27 @@ int launch_dh(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stre
 }  // namespace
 
 int acattn_launch_bwd_fast(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
+int acattn_launch_bwd_stream(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
+
+namespace {
+int g_bwd_kernel = ACATTN_BWD_AUTO;
+}
+int acattn_bwd_kernel_choice(int which) {
+  const int old = g_bwd_kernel;
+  if (which >= ACATTN_BWD_AUTO && which <= ACATTN_BWD_ROW) g_bwd_kernel = which;
+  return old;
+}
 
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
-  const int rc_fast = acattn_launch_bwd_fast(p, io, stream);  // training hot path (L <= 64); -100 = not applicable
+  // training hot paths (structured mask, counter RNG, gate, two_level), -100 = not applicable:
+  //   L <= 64   row-resident kernel, one recomputation (acattn_bwd_fast.hip)
+  //   L >  64   streaming two-kernel backward (acattn_bwd_stream.hip; needs io.workspace)
+  const int which = g_bwd_kernel;
+  if ((which == ACATTN_BWD_AUTO && p.L > 64) || which == ACATTN_BWD_STREAM) {
+    const int rc_stream = acattn_launch_bwd_stream(p, io, stream);
+    if (rc_stream != -100) return rc_stream;
+  }
+  const int rc_fast = acattn_launch_bwd_fast(p, io, stream);
   if (rc_fast != -100) return rc_fast;
   if (!p.two_level) {
     acattn_set_error("backward supports two_level = 1 only (every shipped reference config)");

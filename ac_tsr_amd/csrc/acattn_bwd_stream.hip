@@ -1,0 +1,714 @@
+// Backward of the fused calibrated attention, streaming form (any L <= 208): two kernels, no score tile ever kept
+// across key tiles, no LDS staging, no float atomics on activations.
+//
+// Why.  The row-resident backward kernels (acattn_bwd.hip, acattn_bwd_fast.hip) hold a query block's whole row of
+// P, M and their cotangents in registers: at L = 200 that is 512 registers plus 3.5 KB of scratch per lane, one wave
+// per SIMD, and 7 ms per launch at B = 512 (the forward: 0.36 ms).  Every probability tensor of the layer can be
+// rebuilt tile by tile from the five log-normalisers the forward saved, and the five row scalars the chained
+// soft-max backward needs
+//     da = <A_p, dA_p>   dc = <A_w, dA_w>   r1 = <A_c, dA_c>   sP = <P, dP>   sM = <M, dM>
+// are AFFINE in each other with tile-local coefficients (dA_c, dP, dM are linear in dc, r1, da), so ONE sweep over
+// the key tiles accumulates twelve sums from which all five follow.  That gives
+//
+//   row kernel   one wave per (sequence, head, 16-row query block):
+//                sweep 1 -> the five row scalars (kept in a small workspace for the key kernel);
+//                sweep 2 -> dS, dSa tile by tile -> dq, dqa (MFMA, accumulated in registers), the gate-logit
+//                partials, the query halves of the calibrator parameter gradients;
+//   key kernel   one wave per (sequence, head, 16-key tile): sweeps the query blocks that see the tile, rebuilds
+//                the same tiles, turns them through a 5 KB LDS scratch and accumulates dK, dKa, dV in registers
+//                (MFMA), plus the key halves of the calibrator parameter gradients.
+//
+// Three recomputations of the forward's elementwise work instead of one, but at 2-3 waves per SIMD with nothing
+// spilled, and a grid of thousands of independent waves.  Same mathematics as acattn_bwd_fast.hip (which stays the
+// L <= 64 path: there the row fits comfortably and one recomputation wins).
+// Reference: recbole/model/layers.py:657-742, 883-951 (what is differentiated).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "acattn_common.h"
+
+namespace {
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float and_bits(float x, int m) { return __uint_as_float(__float_as_uint(x) & (uint32_t)m); }
+__device__ __forceinline__ float hsum(const f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+__device__ __forceinline__ float row16_sum(float v) {  // over the 16 lanes of a DPP row (same g, all c)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  return v;
+}
+
+constexpr int NSC = 8;  // floats per row in the workspace: da, dc, r1, sP, sM, (3 spare)
+
+// Everything a lane knows about ITS query row (row i0 + c of one query block) that does not depend on the key tile.
+template <int DH>
+struct Row {
+  static constexpr int KS = DH / 4;
+  float qf[KS], qaf[KS];    // B operands of S^T = K.Q^T and Sa^T = Ka.Qa^T
+  float gaf[KS], gcf[KS];   // d_ctx_attacked / d_ctx_calibrated of the row (B operands of dA^T = V.dctx^T)
+  float ao2, ad;            // query halves of the order (exp2 domain) / distance affines
+  float lx2, ly2, lu2, lv2, lw2;  // the forward's log-normalisers, exp2 domain, dead-row shift removed
+  int i;
+  bool row_ok, dead;
+  uint32_t rng_row;
+};
+
+// Constants of a launch (wave-uniform).
+struct Consts {
+  float inv_sqrt, scale2, nc2, s2, sc, keep_scale, p_drop;
+  bool has_drop, causal;
+  RngKey rkey;
+};
+
+// One (query block, key tile) pair, forward part: every probability tensor of the layer, in the D layout of
+// S^T = K.Q^T (lane (c, g): query row c, keys 16 t + 4 g + r).
+struct Tile {
+  f4 Pt, Mt;        // softmax(x), softmax(y) before dropout
+  f4 P, M;          // after dropout (M is the layer's attack mask)
+  f4 Ap, Ac, Aw;    // perturbed, calibrated, combined attention
+  f4 gt, ex1, nz;   // gate, exp(1 - M), noise
+  f4 dAp, dAw;      // cotangents of A_p and A_w (dctx . V^T)
+  f4 pr, val, df;   // spatial calibrator: sigmoid(o), its log argument, distance residual
+  uint32_t ka, km;  // dropout keep bits
+  int eb[4];        // -1 where the key may receive probability mass
+};
+
+template <int DH>
+__device__ __forceinline__ void tile_forward(const Row<DH>& R, const Consts& K, const f4 (&k4)[DH / 16], const f4 (&ka4)[DH / 16],
+                                             const f4 (&v4)[DH / 16], const f4 co4, const f4 cd4, const f4 gl, const int t,
+                                             const int g, const uint32_t eb4, const uint32_t ab4, const bool order_select,
+                                             Tile& T) {
+  constexpr int KS = DH / 4;
+  f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS, aP = aS, aW = aS;
+#pragma unroll
+  for (int s4 = 0; s4 < KS / 4; ++s4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      aS = mfma16(k4[s4][e], R.qf[4 * s4 + e], aS);
+      aM = mfma16(ka4[s4][e], R.qaf[4 * s4 + e], aM);
+      aP = mfma16(v4[s4][e], R.gaf[4 * s4 + e], aP);
+      aW = mfma16(v4[s4][e], R.gcf[4 * s4 + e], aW);
+    }
+  }
+  T.dAp = aP;
+  T.dAw = aW;
+  const f4 ea = co4 + R.ao2;
+  const int d0 = R.i - (16 * t + 4 * g);
+  f4 lt4, mk4, lg;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    T.eb[r] = sbit(eb4, r);
+    const float pr = fast_rcp(1.0f + ex2(ea[r]));
+    T.pr[r] = pr;
+    float val = 1.0f - pr;
+    if (order_select) val = sbit(ab4, r) ? pr : val;
+    T.val[r] = val;
+    lt4[r] = __builtin_amdgcn_logf((float)(abs(d0 - r) + 1)) * kLn2;
+    mk4[r] = and_bits(ACATTN_MASK_FILL * kLog2e, ~T.eb[r]);
+    lg[r] = __builtin_amdgcn_logf(val + ACATTN_LOG_EPS);
+  }
+  T.df = lt4 - (cd4 + R.ad);
+  f4 x = aS * K.scale2 + mk4;
+  x = lg * K.inv_sqrt + x;
+  x = (T.df * T.df) * K.nc2 + x;
+  const f4 y = aM * K.scale2 + mk4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    T.Pt[r] = ex2(x[r] - R.lx2);
+    T.Mt[r] = ex2(y[r] - R.ly2);
+  }
+  const RngGroup rg = rng_group(K.rkey, R.rng_row, (uint32_t)(4 * t + g), K.p_drop);
+  T.nz = rg.n;
+  T.ka = K.has_drop ? rg.keep_after : 0xFu;
+  T.km = K.has_drop ? rg.keep_mask : 0xFu;
+  T.P = T.Pt * K.keep_scale;
+  T.M = T.Mt * K.keep_scale;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    T.P[r] = keep_and(T.P[r], T.ka, r);
+    T.M[r] = keep_and(T.M[r], T.km, r);
+  }
+  const f4 au = (T.P * T.M + T.nz * (1.0f - T.M)) * kLog2e - R.lu2;  // layers.py:918-919
+  const f4 a1 = T.M * (-kLog2e) + kLog2e;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    T.Ap[r] = and_bits(ex2(au[r]), T.eb[r]);
+    T.ex1[r] = ex2(a1[r]);
+  }
+  const f4 av = (T.P * T.ex1) * kLog2e - R.lv2;  // layers.py:920-921
+  const f4 eg = gl * (-kLog2e);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    T.Ac[r] = and_bits(ex2(av[r]), T.eb[r]);
+    T.gt[r] = fast_rcp(1.0f + ex2(eg[r]));  // layers.py:887
+  }
+  const f4 aw = (T.gt * (T.P - T.Ac) + T.Ac) * kLog2e - R.lw2;  // layers.py:888, 925
+#pragma unroll
+  for (int r = 0; r < 4; ++r) T.Aw[r] = and_bits(ex2(aw[r]), T.eb[r]);
+}
+
+// Backward part once the row scalars are known: dS, dSa (scores), the gate-logit gradient, d o and d d of the two
+// spatial affines, and the scalar's partial.
+__device__ __forceinline__ void tile_backward(const Tile& T, const Consts& K, const float da, const float dc, const float r1,
+                                              const float sP, const float sM, const f4 dMout, const int i, const int j0,
+                                              f4& dS, f4& dSa, f4& dgl, f4& d_o, f4& d_d, float& dsc) {
+  const f4 du = T.Ap * (T.dAp - da);
+  const f4 dw = T.Aw * (T.dAw - dc);  // = d A_g
+  dgl = dw * (T.P - T.Ac) * (T.gt * (1.0f - T.gt));
+  const f4 dac = (1.0f - T.gt) * dw;
+  const f4 dv = T.Ac * (dac - r1);
+  f4 dP = T.gt * dw + dv * T.ex1 + du * T.M;
+  f4 dM = du * (T.P - T.nz) - dv * (T.P * T.ex1) + dMout;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // through the dropouts: kept entries are scaled, dropped ones carry nothing
+    dP[r] = keep_and(dP[r] * K.keep_scale, T.ka, r);
+    dM[r] = keep_and(dM[r] * K.keep_scale, T.km, r);
+  }
+  dS = (T.Pt * (dP - sP)) * K.inv_sqrt;
+  dSa = (T.Mt * (dM - sM)) * K.inv_sqrt;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float sgn = (j0 + r > i) ? 1.0f : -1.0f;  // d val / d sigmoid: +1 for keys after the query, -1 otherwise
+    d_o[r] = dS[r] * (sgn * T.pr[r] * (1.0f - T.pr[r])) * fast_rcp(T.val[r] + ACATTN_LOG_EPS);
+  }
+  d_d = dS * (T.df * K.s2);
+  dsc = hsum(dS * (T.df * T.df)) * (-K.sc);
+}
+
+// 4 floats of a [.., L] row at key offset j0 (rows with L % 4 != 0 are only dword aligned; the last group is ragged)
+__device__ __forceinline__ f4 load_seg(const float* row, int j0, int L, bool ok) {
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (ok && j0 < L) {
+    if (j0 + 3 < L) {
+      v = *(const f4u*)(row + j0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (j0 + r < L) v[r] = row[j0 + r];
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ void store_seg(float* row, int j0, int L, bool ok, const f4 val) {
+  if (!ok || j0 >= L) return;
+  if (j0 + 3 < L) {
+    *(f4u*)(row + j0) = val;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (j0 + r < L) row[j0 + r] = val[r];
+  }
+}
+
+// Wave-level description of a sequence's key flags (up to 208 keys: four 64-bit ballots).
+struct KeyFlags {
+  unsigned long long vk[4];
+  int first_valid, nt_valid;
+  bool any_valid;
+};
+__device__ __forceinline__ KeyFlags load_key_flags(const uint8_t* key_valid, size_t rowbase, int L, int nT, int lane) {
+  KeyFlags F;
+  F.any_valid = false;
+  F.first_valid = L;
+  int last_valid = -1;
+#pragma unroll
+  for (int q = 3; q >= 0; --q) {
+    const uint8_t b = (64 * q + lane < L) ? key_valid[rowbase + 64 * q + lane] : (uint8_t)0;
+    F.vk[q] = __ballot(b != 0);
+    if (F.vk[q]) {
+      F.any_valid = true;
+      F.first_valid = 64 * q + __ffsll((long long)F.vk[q]) - 1;
+      if (last_valid < 0) last_valid = 64 * q + 63 - __clzll((long long)F.vk[q]);
+    }
+  }
+  F.nt_valid = F.any_valid ? (last_valid >> 4) + 1 : nT;
+  return F;
+}
+// the lane's 4 mask bits of key tile t for query row i: `eb` = may receive probability mass, `ab` = key after the query
+__device__ __forceinline__ void tile_bits(const KeyFlags& F, int t, int g, int i, int L, bool causal, bool row_ok, bool dead,
+                                          uint32_t& eb, uint32_t& ab) {
+  const uint32_t vn = (uint32_t)(F.vk[t >> 2] >> (16 * (t & 3) + 4 * g)) & 0xFu;
+  const int d0 = i - 16 * t - 4 * g;
+  const uint32_t cn = d0 >= 3 ? 0xFu : (d0 < 0 ? 0u : (2u << d0) - 1u);
+  const int n_in = min(max(L - 16 * t - 4 * g, 0), 4);
+  const uint32_t inr = (1u << n_in) - 1u;
+  ab = ~cn & 0xFu;
+  eb = dead ? inr : (causal ? (vn & cn) : vn);
+  if (!row_ok) eb = 0u;  // rows past L: everything masked, every probability exactly 0
+}
+
+// Query-row state of block qb for lane c.
+template <int DH>
+__device__ __forceinline__ void load_row(const acattn_problem& P, const acattn_bwd_io& IO, const KeyFlags& F, size_t rowbase,
+                                         size_t bh, int hoff, int qb, int c, int g, Row<DH>& R) {
+  constexpr int KS = DH / 4;
+  const int L = P.L, H = P.H;
+  R.i = 16 * qb + c;
+  R.row_ok = R.i < L;
+  const size_t off = (rowbase + (R.row_ok ? R.i : 0)) * H + hoff + KS * g;
+  float ao = 0.f, adv = 0.f;
+#pragma unroll
+  for (int s4 = 0; s4 < KS / 4; ++s4) {
+    const f4 tq = *(const f4*)(P.q + off + 4 * s4), ta = *(const f4*)(P.qa + off + 4 * s4);
+    f4 ga = {0.f, 0.f, 0.f, 0.f}, gc = ga;
+    if (IO.d_ctx_attacked) ga = *(const f4*)(IO.d_ctx_attacked + off + 4 * s4);
+    if (IO.d_ctx_calibrated) gc = *(const f4*)(IO.d_ctx_calibrated + off + 4 * s4);
+    const f4 a = *(const f4*)(P.w_order + KS * g + 4 * s4), d = *(const f4*)(P.w_dist + KS * g + 4 * s4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      R.qf[4 * s4 + e] = R.row_ok ? tq[e] : 0.f;
+      R.qaf[4 * s4 + e] = R.row_ok ? ta[e] : 0.f;
+      R.gaf[4 * s4 + e] = R.row_ok ? ga[e] : 0.f;
+      R.gcf[4 * s4 + e] = R.row_ok ? gc[e] : 0.f;
+      ao += R.qf[4 * s4 + e] * a[e];
+      adv += R.qf[4 * s4 + e] * d[e];
+    }
+  }
+  ao = quad_sum(ao) + P.b_order[0];
+  R.ad = quad_sum(adv) + P.b_dist[0];
+  R.ao2 = -kLog2e * ao;
+  // a row without any allowed key (left padding) spreads over every key < L; the forward added its -10000 shift to
+  // the stored normalisers (acattn_fwd_body.inc), which is taken out again here
+  R.dead = P.causal ? F.first_valid > R.i : !F.any_valid;
+  const float sh = R.dead ? ACATTN_MASK_FILL : 0.f;
+  const float* sp = IO.row_stats + (bh * L + (R.row_ok ? R.i : 0)) * ACATTN_NSTAT;
+  const f4 s0 = *(const f4*)sp;
+  const float s4v = sp[4];
+  R.lx2 = (s0[0] - sh) * kLog2e;
+  R.ly2 = (s0[1] - sh) * kLog2e;
+  R.lu2 = (s0[2] - sh) * kLog2e;
+  R.lv2 = (s0[3] - sh) * kLog2e;
+  R.lw2 = (s4v - sh) * kLog2e;
+  R.rng_row = (uint32_t)(bh * L + R.i);
+}
+
+__device__ __forceinline__ Consts make_consts(const acattn_problem& P, int DH) {
+  Consts K;
+  K.sc = P.scalar[0];
+  K.s2 = K.sc * K.sc;
+  K.inv_sqrt = 1.0f / sqrtf((float)DH);
+  K.scale2 = K.inv_sqrt * kLog2e;
+  K.nc2 = -(0.5f * K.s2 * K.scale2);
+  K.p_drop = P.p_drop;
+  K.has_drop = P.p_drop > 0.f;
+  K.keep_scale = K.has_drop ? fast_rcp(1.0f - P.p_drop) : 1.0f;
+  K.causal = P.causal != 0;
+  K.rkey = rng_key(P.seed + (P.seed_device ? *P.seed_device : 0ull));
+  return K;
+}
+
+// Key-tile operands in the two shapes the MFMAs want them:
+//   row fragment  X[16 t + c][KS g ..]   (A operand of  X . frag^T : scores, dA)
+//   col fragment  X[16 t + 4 g + r][16 dt + c]   (A operand of  X^T . tile^T : dq, and with query rows: dk, dv)
+template <int DH>
+__device__ __forceinline__ void row_frag(const float* X, size_t rowbase, int H, int hoff, int row0, int L, int c, int g,
+                                         f4 (&out)[DH / 16]) {
+  const float* p = X + (rowbase + min(row0 + c, L - 1)) * H + hoff + (DH / 4) * g;
+#pragma unroll
+  for (int s4 = 0; s4 < DH / 16; ++s4) out[s4] = *(const f4*)(p + 4 * s4);
+}
+template <int DH>
+__device__ __forceinline__ void col_frag(const float* X, size_t rowbase, int H, int hoff, int row0, int L, int c, int g,
+                                         float (&out)[4][DH / 16]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + 4 * g + r;
+    const float* p = X + (rowbase + min(row, L - 1)) * H + hoff + c;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) out[r][dt] = (X && row < L) ? p[16 * dt] : 0.f;
+  }
+}
+// key halves of the two affines for the lane's 4 keys of a tile, from the K row fragment (lane c holds key 16 t + c)
+template <int DH>
+__device__ __forceinline__ void key_affine(const f4 (&k4)[DH / 16], const float (&wko)[DH / 4], const float (&wkd)[DH / 4], int g,
+                                           f4& co4, f4& cd4) {
+  float co = 0.f, cd = 0.f;
+#pragma unroll
+  for (int s4 = 0; s4 < DH / 16; ++s4)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      co += k4[s4][e] * wko[4 * s4 + e];
+      cd += k4[s4][e] * wkd[4 * s4 + e];
+    }
+  co = quad_sum(co);
+  cd = quad_sum(cd);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int src = 4 * (4 * g + r);
+    co4[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, co)));
+    cd4[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, cd)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// row kernel
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ void __launch_bounds__(64, 2) acattn_bwd_row_kernel(const acattn_problem P, const acattn_bwd_io IO, float* __restrict__ ws) {
+  constexpr int KS = DH / 4, DT = DH / 16;
+  const int L = P.L, H = P.H, nh = P.n_heads;
+  const int nT = (L + 15) >> 4;
+  const int n_items = P.B * nh;
+  const bool causal = P.causal != 0;
+  const int rank = blockIdx.x / n_items, item = blockIdx.x - rank * n_items;
+  const int qb = causal ? nT - 1 - rank : rank;  // heaviest query blocks first
+  int b, h;
+  decode_block(item, P.B, nh, b, h);
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const size_t rowbase = (size_t)b * L, bh = (size_t)b * nh + h;
+  const int hoff = h * DH;
+  const bool full = !IO.attack_only;
+  const uint32_t prow_base = (uint32_t)bh * L * (uint32_t)L;
+
+  const KeyFlags F = load_key_flags(P.key_valid, rowbase, L, nT, lane);
+  Row<DH> R;
+  load_row<DH>(P, IO, F, rowbase, bh, hoff, qb, c, g, R);
+  const uint32_t prow = prow_base + (uint32_t)(R.row_ok ? R.i : 0) * (uint32_t)L;
+  float* wrow = ws + (bh * L + (R.row_ok ? R.i : 0)) * NSC;
+
+  // a query block none of whose rows carries a cotangent contributes nothing anywhere
+  const bool block_active = !IO.active_qblocks || IO.d_attack_mask || ((IO.active_qblocks[b] >> qb) & 1u);
+  if (!block_active) {
+    if (R.row_ok) {
+      const f4 z = {0.f, 0.f, 0.f, 0.f};
+      const uint32_t off = ((uint32_t)rowbase + R.i) * H + hoff + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        if (full) *(f4*)(IO.dq + off + 16 * dt) = z;
+        *(f4*)(IO.dqa + off + 16 * dt) = z;
+      }
+      if (full && IO.dgate_logits)
+        for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, 16 * t + 4 * g, L, true, z);
+      if (g == 0) {
+        *(f4*)wrow = z;
+        *(f4*)(wrow + 4) = z;
+      }
+    }
+    return;
+  }
+
+  const Consts K = make_consts(P, DH);
+  float wko[KS], wkd[KS];
+#pragma unroll
+  for (int s4 = 0; s4 < KS / 4; ++s4) {
+    const f4 ak = *(const f4*)(P.w_order + DH + KS * g + 4 * s4), dk = *(const f4*)(P.w_dist + DH + KS * g + 4 * s4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wko[4 * s4 + e] = ak[e] * -kLog2e;
+      wkd[4 * s4 + e] = dk[e];
+    }
+  }
+  const int i0 = 16 * qb;
+  const bool rows_see_a_key = causal ? F.first_valid <= i0 : F.any_valid;
+  const int nt = rows_see_a_key ? min(causal ? min(nT, qb + 1) : nT, F.nt_valid) : nT;
+  const bool order_select = !causal || __ballot(R.dead) != 0ull;
+  const float* grow = P.gate_logits + (rowbase + (R.row_ok ? R.i : 0)) * L;
+  const float* dmrow = IO.d_attack_mask ? IO.d_attack_mask + prow : nullptr;
+
+  auto build = [&](int t, Tile& T) {
+    f4 k4[DT], ka4[DT], v4[DT];
+    row_frag<DH>(P.k, rowbase, H, hoff, 16 * t, L, c, g, k4);
+    row_frag<DH>(P.ka, rowbase, H, hoff, 16 * t, L, c, g, ka4);
+    row_frag<DH>(P.v, rowbase, H, hoff, 16 * t, L, c, g, v4);
+    const f4 gl = load_seg(grow, 16 * t + 4 * g, L, R.row_ok);
+    f4 co4, cd4;
+    key_affine<DH>(k4, wko, wkd, g, co4, cd4);
+    uint32_t eb4, ab4;
+    tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
+    tile_forward<DH>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+  };
+
+  // ---- sweep 1: the twelve row sums ---------------------------------------------------------------------------------
+  float s_da = 0.f, s_dc = 0.f, s_r1a = 0.f, s_r1b = 0.f, cP0 = 0.f, cPc = 0.f, cPr = 0.f, cPa = 0.f, cM0 = 0.f, cMc = 0.f,
+        cMr = 0.f, cMa = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    Tile T;
+    build(t, T);
+    const f4 dMout = dmrow ? load_seg(dmrow, 16 * t + 4 * g, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 apd = T.Ap * T.dAp;
+    const f4 alpha = T.Aw * T.dAw, beta = T.Aw;
+    const f4 gam = T.Ac * (1.0f - T.gt);
+    const f4 PE = T.P * T.ex1;
+    s_da += hsum(apd);
+    s_dc += hsum(alpha);
+    s_r1a += hsum(gam * alpha);
+    s_r1b += hsum(gam * beta);
+    cP0 += hsum(T.P * (T.gt * alpha + T.ex1 * (gam * alpha) + T.M * apd));
+    cPc += hsum(T.P * (T.gt * beta + T.ex1 * (gam * beta)));
+    cPr += hsum(PE * T.Ac);
+    cPa += hsum(T.P * (T.M * T.Ap));
+    cM0 += hsum(T.M * ((T.P - T.nz) * apd - PE * (gam * alpha) + dMout));
+    cMc += hsum(T.M * (PE * (gam * beta)));
+    cMr += hsum(T.M * (PE * T.Ac));
+    cMa += hsum(T.M * ((T.P - T.nz) * T.Ap));
+  }
+  const float da = quad_sum(s_da), dc = quad_sum(s_dc);
+  const float r1 = quad_sum(s_r1a) - dc * quad_sum(s_r1b);
+  const float sP = quad_sum(cP0) - dc * quad_sum(cPc) - r1 * quad_sum(cPr) - da * quad_sum(cPa);
+  const float sM = quad_sum(cM0) + dc * quad_sum(cMc) + r1 * quad_sum(cMr) - da * quad_sum(cMa);
+  if (R.row_ok && g == 0) {
+    *(f4*)wrow = f4{da, dc, r1, sP};
+    *(f4*)(wrow + 4) = f4{sM, 0.f, 0.f, 0.f};
+  }
+
+  // ---- sweep 2: dS, dSa -> dq, dqa; gate partials; query halves of the parameter gradients -------------------------------
+  f4 oq[DT], oqa[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    oq[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    oqa[dt] = oq[dt];
+  }
+  float da_o = 0.f, da_d = 0.f, dsc_acc = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    Tile T;
+    build(t, T);
+    const int j0 = 16 * t + 4 * g;
+    const f4 dMout = dmrow ? load_seg(dmrow, j0, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
+    f4 dS, dSa, dgl, d_o, d_d;
+    float dsc;
+    tile_backward(T, K, da, dc, r1, sP, sM, dMout, R.i, j0, dS, dSa, dgl, d_o, d_d, dsc);
+    if (full && IO.dgate_logits) store_seg(IO.dgate_logits + prow, j0, L, R.row_ok, dgl);
+    da_o += hsum(d_o);
+    da_d += hsum(d_d);
+    dsc_acc += dsc;
+    float kc[4][DT], kac[4][DT];
+    if (full) col_frag<DH>(P.k, rowbase, H, hoff, 16 * t, L, c, g, kc);
+    col_frag<DH>(P.ka, rowbase, H, hoff, 16 * t, L, c, g, kac);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        if (full) oq[dt] = mfma16(kc[r][dt], dS[r], oq[dt]);
+        oqa[dt] = mfma16(kac[r][dt], dSa[r], oqa[dt]);
+      }
+  }
+  if (full && IO.dgate_logits)
+    for (int t = nt; t < nT; ++t) store_seg(IO.dgate_logits + prow, 16 * t + 4 * g, L, R.row_ok, f4{0.f, 0.f, 0.f, 0.f});
+  da_o = quad_sum(da_o);
+  da_d = quad_sum(da_d);
+  dsc_acc = quad_sum(dsc_acc);
+  if (R.row_ok) {
+    const uint32_t off = ((uint32_t)rowbase + R.i) * H + hoff + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      // rank-1 terms of dq: query halves of the affine weights in the lane's output-column order
+      const f4 wo_lo = *(const f4*)(P.w_order + 16 * dt + 4 * g), wd_lo = *(const f4*)(P.w_dist + 16 * dt + 4 * g);
+      if (full) *(f4*)(IO.dq + off + 16 * dt) = oq[dt] + da_o * wo_lo + da_d * wd_lo;
+      *(f4*)(IO.dqa + off + 16 * dt) = oqa[dt];
+    }
+  }
+  if (!full) return;  // the parameter partials are not read either
+  // query halves of dw_order / dw_dist, db_order, db_dist, d scalar: summed over the block's 16 rows, then added to the
+  // (sequence, head) partial row (a few hundred float atomics per launch row; the rows were zeroed by the launcher)
+  const int stride_w = IO.part_stride ? IO.part_stride : 2 * DH, stride_s = IO.part_stride ? IO.part_stride : 4;
+  const float ro = R.row_ok ? 1.0f : 0.0f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float vo = row16_sum(da_o * R.qf[s] * ro), vd = row16_sum(da_d * R.qf[s] * ro);
+    if (c == 0) {
+      atomicAdd(IO.dw_order_part + bh * stride_w + KS * g + s, vo);
+      atomicAdd(IO.dw_dist_part + bh * stride_w + KS * g + s, vd);
+    }
+  }
+  const float so = row16_sum(da_o * ro), sd = row16_sum(da_d * ro), ss = row16_sum(dsc_acc * ro);
+  if (lane == 0) {
+    atomicAdd(IO.dsmall_part + bh * stride_s + 0, so);
+    atomicAdd(IO.dsmall_part + bh * stride_s + 1, sd);
+    atomicAdd(IO.dsmall_part + bh * stride_s + 2, ss);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// key kernel
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ void __launch_bounds__(64, 2) acattn_bwd_key_kernel(const acattn_problem P, const acattn_bwd_io IO, const float* __restrict__ ws) {
+  constexpr int KS = DH / 4, DT = DH / 16;
+  constexpr int TS = 20;  // row stride of a transposed 16 x 16 tile in LDS (16-byte aligned rows, conflict-free reads)
+  __shared__ __attribute__((aligned(16))) float tr[4][16 * TS + 32];
+  const int L = P.L, H = P.H, nh = P.n_heads;
+  const int nT = (L + 15) >> 4;
+  const int n_items = P.B * nh;
+  const bool causal = P.causal != 0;
+  const int rank = blockIdx.x / n_items, item = blockIdx.x - rank * n_items;
+  const int t = rank;  // under the causal mask key tile 0 is seen by every query block: heaviest first
+  int b, h;
+  decode_block(item, P.B, nh, b, h);
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const size_t rowbase = (size_t)b * L, bh = (size_t)b * nh + h;
+  const int hoff = h * DH;
+  const bool full = !IO.attack_only;
+  const uint32_t prow_base = (uint32_t)bh * L * (uint32_t)L;
+
+  const KeyFlags F = load_key_flags(P.key_valid, rowbase, L, nT, lane);
+  const Consts K = make_consts(P, DH);
+  // this wave's 16 keys: row fragments of K, Ka, V (fixed), key halves of the affines
+  f4 k4[DT], ka4[DT], v4[DT];
+  row_frag<DH>(P.k, rowbase, H, hoff, 16 * t, L, c, g, k4);
+  row_frag<DH>(P.ka, rowbase, H, hoff, 16 * t, L, c, g, ka4);
+  row_frag<DH>(P.v, rowbase, H, hoff, 16 * t, L, c, g, v4);
+  float wko[KS], wkd[KS];
+#pragma unroll
+  for (int s4 = 0; s4 < KS / 4; ++s4) {
+    const f4 ak = *(const f4*)(P.w_order + DH + KS * g + 4 * s4), dk = *(const f4*)(P.w_dist + DH + KS * g + 4 * s4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wko[4 * s4 + e] = ak[e] * -kLog2e;
+      wkd[4 * s4 + e] = dk[e];
+    }
+  }
+  f4 co4, cd4;
+  key_affine<DH>(k4, wko, wkd, g, co4, cd4);
+
+  f4 aK[DT], aKa[DT], aV[DT];  // dK^T, dKa^T, dV^T: lane (c, g) holds key 16 t + c, columns 16 dt + 4 g ..
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    aK[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    aKa[dt] = aK[dt];
+    aV[dt] = aK[dt];
+  }
+  f4 dco = {0.f, 0.f, 0.f, 0.f}, dcd = dco;  // d (key half of the affines) of keys 16 t + 4 g + r, summed over queries at the end
+
+  // query blocks that see this key tile: under the causal mask qb >= t; a tile past the last real item is only seen
+  // by blocks with a dead row (they spread over every key)
+  const int qb_lo = causal ? t : 0;
+  for (int qb = qb_lo; qb < nT; ++qb) {
+    const int i0 = 16 * qb;
+    const bool rows_see_a_key = causal ? F.first_valid <= i0 : F.any_valid;
+    const int nt_q = rows_see_a_key ? min(causal ? min(nT, qb + 1) : nT, F.nt_valid) : nT;
+    if (t >= nt_q) continue;  // the row kernel skipped this pair too: it carries no probability mass
+    if (IO.active_qblocks && !IO.d_attack_mask && !((IO.active_qblocks[b] >> qb) & 1u)) continue;
+    Row<DH> R;
+    load_row<DH>(P, IO, F, rowbase, bh, hoff, qb, c, g, R);
+    const bool order_select = !causal || __ballot(R.dead) != 0ull;
+    const float* wrow = ws + (bh * L + (R.row_ok ? R.i : 0)) * NSC;
+    const f4 w0 = *(const f4*)wrow;
+    const float sM = wrow[4];
+    const uint32_t prow = prow_base + (uint32_t)(R.row_ok ? R.i : 0) * (uint32_t)L;
+    const int j0 = 16 * t + 4 * g;
+    const f4 gl = load_seg(P.gate_logits + (rowbase + (R.row_ok ? R.i : 0)) * L, j0, L, R.row_ok);
+    const f4 dMout = IO.d_attack_mask ? load_seg(IO.d_attack_mask + prow, j0, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
+    uint32_t eb4, ab4;
+    tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
+    Tile T;
+    tile_forward<DH>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+    f4 dS, dSa, dgl, d_o, d_d;
+    float dsc;
+    tile_backward(T, K, w0[0], w0[1], w0[2], w0[3], sM, dMout, R.i, j0, dS, dSa, dgl, d_o, d_d, dsc);
+    dco += d_o;
+    dcd += d_d;
+    // turn the four [query c][key 4 g + r] tiles so that the query index becomes the MFMA reduction index
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *(f4*)(&tr[0][c * TS + 4 * g]) = dS;
+    *(f4*)(&tr[1][c * TS + 4 * g]) = dSa;
+    *(f4*)(&tr[2][c * TS + 4 * g]) = T.Ap;
+    *(f4*)(&tr[3][c * TS + 4 * g]) = T.Aw;
+    float qc[4][DT], qac[4][DT], gac[4][DT], gcc[4][DT];
+    if (full) col_frag<DH>(P.q, rowbase, H, hoff, i0, L, c, g, qc);
+    col_frag<DH>(P.qa, rowbase, H, hoff, i0, L, c, g, qac);
+    if (full) col_frag<DH>(IO.d_ctx_attacked, rowbase, H, hoff, i0, L, c, g, gac);
+    if (full) col_frag<DH>(IO.d_ctx_calibrated, rowbase, H, hoff, i0, L, c, g, gcc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float b_s = tr[0][(4 * g + s) * TS + c], b_sa = tr[1][(4 * g + s) * TS + c];
+      const float b_ap = tr[2][(4 * g + s) * TS + c], b_aw = tr[3][(4 * g + s) * TS + c];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        if (full) {
+          aK[dt] = mfma16(qc[s][dt], b_s, aK[dt]);
+          aV[dt] = mfma16(gac[s][dt], b_ap, aV[dt]);
+          aV[dt] = mfma16(gcc[s][dt], b_aw, aV[dt]);
+        }
+        aKa[dt] = mfma16(qac[s][dt], b_sa, aKa[dt]);
+      }
+    }
+  }
+
+  // ---- results: dk (+ rank-1 key-half terms), dka, dv; key halves of the parameter gradients --------------------------------
+  // d co_j, d cd_j: sum over the query lanes; then every lane needs the value of ITS output key 16 t + c
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float so = row16_sum(dco[r]), sd = row16_sum(dcd[r]);
+    if (c == 0) {
+      tr[0][4 * g + r] = so;
+      tr[1][4 * g + r] = sd;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float dco_c = tr[0][c], dcd_c = tr[1][c];
+  const int key = 16 * t + c;
+  if (key < L) {
+    const size_t o = (rowbase + key) * H + hoff + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      *(f4*)(IO.dka + o + 16 * dt) = aKa[dt];
+      if (full) {
+        const f4 wo_hi = *(const f4*)(P.w_order + DH + 16 * dt + 4 * g), wd_hi = *(const f4*)(P.w_dist + DH + 16 * dt + 4 * g);
+        *(f4*)(IO.dk + o + 16 * dt) = aK[dt] + dco_c * wo_hi + dcd_c * wd_hi;
+        *(f4*)(IO.dv + o + 16 * dt) = aV[dt];
+      }
+    }
+  }
+  if (!full) return;
+  // dw_order[dh:] += sum_j d co_j K_j (natural units: co was pre-scaled by -log2e inside the sigmoid argument only)
+  const int stride_w = IO.part_stride ? IO.part_stride : 2 * DH;
+  const float okk = key < L ? 1.0f : 0.0f;
+#pragma unroll
+  for (int s4 = 0; s4 < KS / 4; ++s4)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float vo = row16_sum(dco_c * k4[s4][e] * okk), vd = row16_sum(dcd_c * k4[s4][e] * okk);
+      if (c == 0) {
+        atomicAdd(IO.dw_order_part + bh * stride_w + DH + KS * g + 4 * s4 + e, vo);
+        atomicAdd(IO.dw_dist_part + bh * stride_w + DH + KS * g + 4 * s4 + e, vd);
+      }
+    }
+}
+
+template <int DH>
+int launch_stream(const acattn_problem& p, const acattn_bwd_io& io, float* ws, hipStream_t stream) {
+  const int nT = (p.L + 15) / 16, dh = DH;
+  const size_t rows = (size_t)p.B * p.n_heads;
+  if (!io.attack_only) {  // the parameter partial rows are accumulated with atomics: start from zero
+    if (io.part_stride) {
+      float* lo = std::min(io.dw_order_part, std::min(io.dw_dist_part, io.dsmall_part));
+      if (hipError_t e = hipMemsetAsync(lo, 0, rows * io.part_stride * sizeof(float), stream); e != hipSuccess) return (int)e;
+    } else {
+      (void)hipMemsetAsync(io.dw_order_part, 0, rows * 2 * dh * sizeof(float), stream);
+      (void)hipMemsetAsync(io.dw_dist_part, 0, rows * 2 * dh * sizeof(float), stream);
+      (void)hipMemsetAsync(io.dsmall_part, 0, rows * 4 * sizeof(float), stream);
+    }
+  }
+  const dim3 grid(p.B * p.n_heads * nT), block(64);
+  hipLaunchKernelGGL((acattn_bwd_row_kernel<DH>), grid, block, 0, stream, p, io, ws);
+  hipLaunchKernelGGL((acattn_bwd_key_kernel<DH>), grid, block, 0, stream, p, io, (const float*)ws);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p) { return (int64_t)p.B * p.n_heads * p.L * NSC * sizeof(float); }
+
+// Returns -100 when the problem is outside this path's domain (the caller then uses the row-resident kernels).
+int acattn_launch_bwd_stream(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
+  const bool ok = io.workspace && p.L <= 208 && (int64_t)p.B * p.n_heads * p.L * p.L < (1LL << 30) &&
+                  (int64_t)p.B * p.L * p.H < (1LL << 30) && p.mask_mode == ACATTN_MASK_STRUCTURED &&
+                  p.rng_mode == ACATTN_RNG_COUNTER && p.w_order && p.w_dist && p.adversarial &&
+                  p.combine_option == ACATTN_COMBINE_GATE && p.two_level;
+  if (!ok) return -100;
+  float* ws = (float*)io.workspace;
+  switch (p.H / p.n_heads) {
+    case 16: return launch_stream<16>(p, io, ws, stream);
+    case 32: return launch_stream<32>(p, io, ws, stream);
+    case 64: return launch_stream<64>(p, io, ws, stream);
+  }
+  return -100;
+}

@@ -195,6 +195,8 @@ __device__ __forceinline__ void decode_block(int bid, int B, int nh, int& b, int
 // Host-side launchers (defined in the .hip files, called from acattn_api.hip).
 int acattn_launch_fwd(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
 int acattn_fwd_kernel_choice(int which);
+int acattn_bwd_kernel_choice(int which);
+int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p);
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
 int acattn_launch_rng(int B, int nh, int L, uint64_t seed, float p_drop, float* noise, uint8_t* keep_after,
                       uint8_t* keep_mask, uint8_t* keep_before, hipStream_t stream);

@@ -245,6 +245,9 @@ class _CalibratedAttention(torch.autograd.Function):
         # the three per-(b, head) partial sums share ONE [B*nh, 4*dh + 4] buffer, reduced in a single pass
         width = 4 * dh + 4
         part = torch.empty(B * nh, width, device=q.device, dtype=torch.float32)
+        ws_bytes = int(lib.acattn_calibrated_attention_bwd_workspace_bytes(C.byref(prob)))
+        ws = torch.empty(max(ws_bytes, 4) // 4, device=q.device, dtype=torch.float32)  # row scalars (streaming backward)
+        io.workspace = _ptr(ws)
         base = part.data_ptr()
         io.dw_order_part, io.dw_dist_part, io.dsmall_part = base, base + 4 * 2 * dh, base + 4 * 4 * dh
         io.part_stride = width

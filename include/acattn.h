@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 15
+#define ACATTN_ABI_VERSION 16
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -131,6 +131,9 @@ typedef struct acattn_bwd_io {
   int32_t attack_only;  /* non-zero: the caller will read ONLY dqa and dka (pass 2 of the two-pass trainer through a
                            layer with no attack transform upstream, recbole/trainer/trainer.py:678-684); every other
                            output buffer must still be valid memory but may be left unwritten.  A hint like the above. */
+  void* workspace;      /* optional device scratch of acattn_calibrated_attention_bwd_workspace_bytes(p) bytes (contents
+                           irrelevant).  With it, long sequences (L > 64) take the streaming two-kernel backward
+                           (acattn_bwd_stream.hip); NULL = the row-resident kernels only. */
 } acattn_bwd_io;
 
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
@@ -269,6 +272,9 @@ int acattn_calibrated_attention_fwd(const acattn_problem* p, const acattn_fwd_ou
  * recbole/trainer/trainer.py:677,684). */
 int acattn_calibrated_attention_bwd(const acattn_problem* p, const acattn_bwd_io* io, void* stream);
 
+/* Bytes of `acattn_bwd_io.workspace` for this problem (5 row scalars of the chained soft-max backward per query row). */
+int64_t acattn_calibrated_attention_bwd_workspace_bytes(const acattn_problem* p);
+
 /* Materialise the COUNTER-mode randomness for (seed, shape) so a run can be replayed in EXPLICIT mode. */
 int acattn_rng_materialize(int32_t B, int32_t n_heads, int32_t L, uint64_t seed, float p_drop, float* noise,
                            uint8_t* keep_after, uint8_t* keep_mask, uint8_t* keep_before, void* stream);
@@ -283,6 +289,14 @@ enum {
   ACATTN_FWD_GENERAL = 3  /* acattn_fwd.hip: every option, explicit randomness, probability dumps */
 };
 int acattn_select_forward_kernel(int which);
+
+/* The same for acattn_calibrated_attention_bwd. */
+enum {
+  ACATTN_BWD_AUTO = 0,    /* L <= 64: row-resident tuned kernel; longer: streaming (needs io.workspace); else general */
+  ACATTN_BWD_STREAM = 1,  /* acattn_bwd_stream.hip: row kernel + key kernel, tiles rebuilt from the saved normalisers */
+  ACATTN_BWD_ROW = 2      /* acattn_bwd_fast.hip / acattn_bwd.hip: a query block's whole row in registers */
+};
+int acattn_select_backward_kernel(int which);
 
 #ifdef __cplusplus
 }

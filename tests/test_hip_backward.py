@@ -207,13 +207,30 @@ def test_graph_mode_matches_eager_and_redraws_randomness():
     assert cal.item() < first - 0.3, (first, cal.item())
 
 
+@pytest.fixture
+def backward_kernel():
+    """Pins the backward kernel (acattn_select_backward_kernel) for one test and restores the automatic choice."""
+    from ac_tsr_amd import _lib
+    lib = _lib.load()
+    yield lambda which: lib.acattn_select_backward_kernel(which)
+    lib.acattn_select_backward_kernel(_lib.BWD_AUTO)
+
+
+# (B, L, H, heads, kernel): 2 = row-resident tuned kernel (acattn_bwd_fast.hip, L <= 64), 1 = streaming two-kernel
+# backward (acattn_bwd_stream.hip, L <= 208).  (512, 50, 64, 2) is the shape bench.py trains on.
+_BWD_CASES = [(64, 50, 64, 2, 2), (12, 50, 64, 4, 2), (8, 64, 128, 2, 2), (6, 37, 64, 2, 2), (512, 50, 64, 2, 2),
+              (64, 50, 64, 2, 1), (12, 50, 64, 4, 1), (8, 64, 128, 2, 1), (6, 37, 64, 2, 1),
+              (4, 200, 128, 4, 1), (3, 200, 64, 2, 1), (2, 130, 256, 4, 1), (5, 77, 64, 4, 1)]
+
+
 @pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("p_drop", [0.0, 0.5])
-@pytest.mark.parametrize("shape", [(64, 50, 64, 2), (12, 50, 64, 4), (8, 64, 128, 2), (6, 37, 64, 2)])
-def test_fast_training_backward_equals_general_backward(causal, p_drop, shape):
-    """acattn_bwd_fast.hip (counter RNG, gate, structured mask) against the general backward fed the same draws as
-    explicit tensors (itself pinned to the oracle's autograd above): every gradient of the fused operator."""
-    B, L, H, nh = shape
+@pytest.mark.parametrize("case", _BWD_CASES, ids=lambda c: "B%d_L%d_H%d_h%d_k%d" % c)
+def test_fast_training_backward_equals_general_backward(causal, p_drop, case, backward_kernel):
+    """The tuned backward kernels (counter RNG, gate, structured mask) against the general backward fed the same draws
+    as explicit tensors (itself pinned to the oracle's autograd above): every gradient of the fused operator."""
+    B, L, H, nh, which = case
+    backward_kernel(which)
     g = torch.Generator().manual_seed(21)
     mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
     base = {k: mk(B, L, H) for k in ("q", "k", "v", "qa", "ka")}
