@@ -804,10 +804,11 @@ int acattn_bwd_kernel_choice(int which) {
 
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
   // training hot paths (structured mask, counter RNG, gate, two_level), -100 = not applicable:
-  //   L <= 64   row-resident kernel, one recomputation (acattn_bwd_fast.hip)
-  //   L >  64   streaming two-kernel backward (acattn_bwd_stream.hip; needs io.workspace)
+  //   streaming two-kernel backward (acattn_bwd_stream.hip; needs io.workspace): the default.  B = 512, all three
+  //   cotangents: L = 50 57 + 41 us against 131 us row-resident; L = 200 (H = 128, 4 heads) 0.87 ms against 7.0 ms;
+  //   row-resident kernel, one recomputation (acattn_bwd_fast.hip, L <= 64): ACATTN_BWD_ROW, or no workspace
   const int which = g_bwd_kernel;
-  if ((which == ACATTN_BWD_AUTO && p.L > 64) || which == ACATTN_BWD_STREAM) {
+  if (which == ACATTN_BWD_AUTO || which == ACATTN_BWD_STREAM) {
     const int rc_stream = acattn_launch_bwd_stream(p, io, stream);
     if (rc_stream != -100) return rc_stream;
   }

@@ -33,7 +33,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default=None,
+                    help="BASELINE.json configs[1..4] presets: cfg2/cfg3 = the default L=50 d=64 workload (the metric's "
+                         "configuration; cfg2 is its spatial-only kernel line), cfg4 = L=200 d=128 4 heads AC-SASRec, "
+                         "cfg5 = L=200 d=256 4 heads AcBERT4Rec (bidirectional mask)")
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="sequences per GPU")
     ap.add_argument("--seq-len", type=int, default=50)
@@ -49,9 +53,22 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-full-schedule", action="store_true",
                     help="skip the extra timing of the step with the reference's full (unpruned) schedule")
+    ap.add_argument("--fwd-kernel", choices=["auto", "stream", "staged", "general"], default="auto",
+                    help="pin the attention forward kernel (acattn_select_forward_kernel); measurements only")
+    ap.add_argument("--bwd-kernel", choices=["auto", "stream", "row"], default="auto",
+                    help="pin the attention backward kernel (acattn_select_backward_kernel); measurements only")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffer, graph without optimizer) even on one GPU")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.model = "ACSASRec"
+    if a.config == "cfg4":  # "Yelp-scale synthetic, L=200 d=128 4 heads"; the catalogue size is ours (stated in the line)
+        a.seq_len, a.hidden, a.heads, a.inner = 200, 128, 4, 512
+    elif a.config == "cfg5":  # "AC-BERT4Rec variant (bidirectional mask) L=200 d=256"
+        # heads: BASELINE leaves them open; 4 -> head size 64 (the reference default of 2 would need head size 128,
+        # which the kernels do not cover).  20,000 items: the masked-slot CE at d=256 goes through materialised
+        # [rows, N] logits (the fused CE covers d <= 128) and ~20 k rows x 100 k items would be 8 GB per tensor.
+        a.seq_len, a.hidden, a.heads, a.inner, a.items, a.model = 200, 256, 4, 1024, 20000, "AcBERT4Rec"
+    return a
 
 
 def synthetic_batch(B, L, n_items, gen, device):
@@ -64,7 +81,8 @@ def synthetic_batch(B, L, n_items, gen, device):
 
 
 def model_config(a):
-    return dict(n_layers=a.layers, n_heads=a.heads, hidden_size=a.hidden, inner_size=a.inner, hidden_dropout_prob=0.5,
+    extra = dict(mask_ratio=0.2) if a.model == "AcBERT4Rec" else {}
+    return dict(**extra, n_layers=a.layers, n_heads=a.heads, hidden_size=a.hidden, inner_size=a.inner, hidden_dropout_prob=0.5,
                 attn_dropout_prob=0.5, hidden_act='gelu', layer_norm_eps=1e-12, initializer_range=0.02, loss_type='CE',
                 combine_option='gate', two_level=True, use_order=True, use_distance=True, rich_calibrated_combine='none',
                 use_position_embedding=False, trainable_mask_loss_weight=False, mask_loss_weight=0.03,
@@ -98,7 +116,7 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
         p = _lib.Problem()
         p.B, p.L, p.H, p.n_heads = B, L, H, nh
         p.q, p.k, p.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
-        p.mask_mode, p.causal, p.key_valid = _lib.MASK_STRUCTURED, 1, kv.data_ptr()
+        p.mask_mode, p.causal, p.key_valid = _lib.MASK_STRUCTURED, int(a.model != "AcBERT4Rec"), kv.data_ptr()
         p.w_order, p.b_order, p.w_dist, p.b_dist, p.scalar = (t.data_ptr() for t in (w_order, b_order, w_dist, b_dist, scalar))
         p.adversarial = int(adversarial)
         p.two_level = 1
@@ -121,7 +139,7 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
             if rc:
                 _lib.check(rc, "fwd")
 
-    launch(20)
+    launch(min(20, iters))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     rounds = []
@@ -134,12 +152,12 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
     best = sum(rounds) / len(rounds)  # average launch duration over all timed launches
     dh = H // nh
     flavour = "true" if adversarial else "false"
-    if 48 < L <= 64:
-        kernel_name = "acattn_fwd_dma_kernel<%d,%s>" % (dh, flavour)
-    elif L <= 48:
-        kernel_name = "acattn_fwd_fast_kernel<%d,%s>" % (dh, flavour)
-    else:
-        kernel_name = "acattn_fwd_kernel<%d,%d,...>" % (dh, 8 if L <= 128 else 13)
+    # the automatic choice of acattn_calibrated_attention_fwd for this configuration (csrc/acattn_fwd.hip)
+    kernel_name = "acattn_fwd_stream_kernel<%d,%d,%s>" % (dh, 4 if L <= 64 else 13, flavour)
+    if a.fwd_kernel == "staged" and L <= 64:
+        kernel_name = ("acattn_fwd_dma_kernel<%d,%s>" if L > 48 else "acattn_fwd_fast_kernel<%d,%s>") % (dh, flavour)
+    elif a.fwd_kernel == "general":
+        kernel_name = "acattn_fwd_kernel<%d,%d,...>" % (dh, 4 if L <= 64 else (8 if L <= 128 else 13))
     alg = ops.fwd_algorithmic_bytes(B, L, H, nh, adversarial, "gate")
     achieved = alg / (best * 1e-6) / 1e9
     traffic, traffic_src = None, None
@@ -185,14 +203,25 @@ def cpu_baseline(a, state_dict, steps):
             P[n].grad = g if g is not None else torch.zeros_like(P[n])
         opt.step()
 
-    step(32)  # thread-pool / allocator warm-up
+    # bounded sample: the reference algorithm materialises [B, h, L, L, 2 dh] (21 GB at B=512, L=200, d=128), so long
+    # sequences are timed on 16 sequences per step
+    cpu_batch = a.batch if a.seq_len <= 64 else 16
+    step(min(32, cpu_batch))  # thread-pool / allocator warm-up
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(a.batch)
+        step(cpu_batch)
     dt = time.perf_counter() - t0
-    return {"value": round(steps * a.batch / dt, 1), "unit": "user-sequences/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{steps} full steps (fwd + two-pass bwd + Adam) of B={a.batch} L={a.seq_len} d={a.hidden} "
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(steps * cpu_batch / dt, 1), "unit": "user-sequences/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "cpu_model": cpu_model, "os_cpu_count": os.cpu_count(),
+            "sample": f"{steps} full steps (fwd + two-pass bwd + Adam) of B={cpu_batch} L={a.seq_len} d={a.hidden} "
                       f"h={a.heads} {a.layers} layers N={a.items}, oracle/ac_tsr_ref.py (materialised q||k concat), "
                       f"{dt:.1f} s wall"}
 
@@ -210,7 +239,9 @@ def main():
     device = torch.device("cuda", local)
 
     import ac_tsr_amd as A
-    from ac_tsr_amd import parallel
+    from ac_tsr_amd import _lib, parallel
+    _lib.load().acattn_select_forward_kernel(["auto", "stream", "staged", "general"].index(a.fwd_kernel))
+    _lib.load().acattn_select_backward_kernel(["auto", "stream", "row"].index(a.bwd_kernel))
 
     if world > 1:
         parallel.init_distributed("nccl")
@@ -223,7 +254,9 @@ def main():
         return
 
     torch.manual_seed(42)  # config/*.yaml seed: 42 -- identical initial parameters on every rank
-    model = A.ACSASRec(A.DictConfig(model_config(a)), A.ItemCount(a.items)).to(device)
+    model = getattr(A, a.model)(A.DictConfig(model_config(a)), A.ItemCount(a.items)).to(device)
+    if a.model == "AcBERT4Rec":
+        model.cloze_on_device = True  # the cloze batch is built with tensor ops: the whole step replays as a graph
     parallel.broadcast_parameters(model)
     sync = parallel.GradSynchronizer.for_two_pass_model(model) if (world > 1 or a.force_grad_sync) else None
     trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model, grad_sync=sync)
@@ -242,8 +275,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = None
+    # one event per step boundary (recorded inside the timed region: microseconds of host time per step) for the
+    # median / min / max of the step time; `value` and `ms_per_step` stay the wall clock over all K steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    marks[0].record()
     for i in range(a.steps):
         last = trainer.train_step(pool[i % len(pool)])
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -253,6 +291,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     att, cal = (float(x.detach()) for x in last)
     if not (att == att and cal == cal):
         raise SystemExit("Training loss is nan")
@@ -283,12 +322,15 @@ def main():
             "metric": "user-sequences/sec fwd+bwd, AC-SASRec L=50 d=64, 1/2/4/8 MI355X",
             "value": round(world * a.batch * a.steps / dt, 1), "unit": "user-sequences/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "ms_per_step_median": round(per_step[len(per_step) // 2], 3), "ms_per_step_min": round(per_step[0], 3),
+            "ms_per_step_max": round(per_step[-1], 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"AC-SASRec full training step (spatial + adversarial calibrators, BASELINE configs[2]; "
-                            f"configs[1] spatial-only kernel under roofline_spatial_only), synthetic {a.items}-item "
-                            f"catalogue, B={a.batch}/GPU L={a.seq_len} d={a.hidden} h={a.heads} {a.layers} layers "
-                            f"inner={a.inner}, CE loss, two-pass backward + Adam",
+                "workload": (f"{a.model} full training step (spatial + adversarial calibrators, BASELINE "
+                             f"configs[{ {None: 2, 'cfg2': 2, 'cfg3': 2, 'cfg4': 3, 'cfg5': 4}[a.config] }]"
+                             + ("; configs[1] spatial-only kernel under roofline_spatial_only" if a.config in (None, "cfg2", "cfg3") else "")
+                             + f"), synthetic {a.items}-item catalogue, B={a.batch}/GPU L={a.seq_len} d={a.hidden} "
+                             f"h={a.heads} {a.layers} layers inner={a.inner}, CE loss, two-pass backward + Adam"),
                 "global_batch": world * a.batch, "seq_len": a.seq_len, "hidden": a.hidden, "heads": a.heads,
                 "parallelism": f"dp{world}", "launch": "eager" if a.no_graph else "hipGraph replay per step",
                 "final_losses": [round(att, 4), round(cal, 4)],
@@ -298,7 +340,7 @@ def main():
         }
         res["roofline"] = kernel_roofline(a, device, True, a.kernel_iters)
         res["roofline_spatial_only"] = kernel_roofline(a, device, False, a.kernel_iters)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.model == "ACSASRec":
             res["cpu_baseline"] = cpu_baseline(a, init_state, a.cpu_steps)
         else:
             res["cpu_baseline"] = None
