@@ -45,7 +45,11 @@ __global__ void __launch_bounds__(64, (stream_waves<DH, NT>())) acattn_fwd_strea
   const int nT = (L + 15) >> 4;
   const int n_items = P.B * nh;
   const bool causal = P.causal != 0;
-  // heaviest query blocks first: under the causal mask block qb visits qb + 1 key tiles
+  // heaviest query blocks first: under the causal mask block qb visits qb + 1 key tiles.  (Measured alternatives:
+  // the query blocks of one item adjacent on one XCD, for L2 reuse of K / Ka / V -- 23.5 us against 21.2 at L = 50,
+  // 359 against 344 at L = 200; staggered wave starts -- the launch takes exactly the stagger longer: a wave's own
+  // chain of instructions and L2 round trips, not contention, sets its duration; V fragments one tile ahead in
+  // pass 2 like K in pass 1 -- no change.)
   const int rank = blockIdx.x / n_items, item = blockIdx.x - rank * n_items;
   const int qb = causal ? nT - 1 - rank : rank;
   int b, h;
