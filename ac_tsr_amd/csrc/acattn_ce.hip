@@ -136,7 +136,12 @@ __global__ void __launch_bounds__(256) ce_fwd_reduce_kernel(const acattn_ce_prob
     m = mn;
     s = a + b;
   }
-  const long long tgt = P.target[row];
+  // A target outside [0, N) (an ignore_index such as -100, a corrupt label) must not become an out-of-bounds read of
+  // the table: the row is clamped for the address and its loss is NaN, which the trainer's NaN guard reports
+  // (torch's CrossEntropyLoss raises a device assert in this case).
+  const long long tgt_raw = P.target[row];
+  const bool tgt_ok = tgt_raw >= 0 && tgt_raw < P.N;
+  const long long tgt = tgt_ok ? tgt_raw : 0;
   float dot = 0.f;
   for (int d = lane; d < CH; d += 64) dot += P.out[(size_t)row * CH + d] * P.table[(size_t)tgt * CH + d];
 #pragma unroll
@@ -144,7 +149,7 @@ __global__ void __launch_bounds__(256) ce_fwd_reduce_kernel(const acattn_ce_prob
   if (lane == 0) {
     const float l = m + __builtin_amdgcn_logf(s) * kLn2;
     lse[row] = l;
-    row_loss[row] = l - dot;
+    row_loss[row] = tgt_ok ? l - dot : __builtin_nanf("");
   }
 }
 
@@ -451,7 +456,8 @@ __global__ void __launch_bounds__(256) ce_dir_reduce_kernel(const acattn_ce_prob
   if (threadIdx.x < CH) {
     float o = 0.f;
     for (int k = 0; k < GROUPS; ++k) o += facc[k * CH + threadIdx.x];
-    const long long tgt = P.target[row];
+    const long long tgt_raw = P.target[row];
+    const long long tgt = (tgt_raw >= 0 && tgt_raw < P.N) ? tgt_raw : 0;  // see ce_fwd_reduce_kernel
     const float et = P.table[(size_t)tgt * CH + threadIdx.x];
     dir[(size_t)row * CH + threadIdx.x] = o / S - et;
     red[threadIdx.x] = P.out[(size_t)row * CH + threadIdx.x] * et;
@@ -461,8 +467,9 @@ __global__ void __launch_bounds__(256) ce_dir_reduce_kernel(const acattn_ce_prob
     float dot = 0.f;
     for (int k = 0; k < CH; ++k) dot += red[k];
     const float l = m + __builtin_amdgcn_logf(S) * kLn2;
+    const long long tgt_raw = P.target[row];
     lse[row] = l;
-    row_loss[row] = l - dot;
+    row_loss[row] = (tgt_raw >= 0 && tgt_raw < P.N) ? l - dot : __builtin_nanf("");
   }
 }
 
