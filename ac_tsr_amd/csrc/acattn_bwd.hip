@@ -39,7 +39,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // BIG = the key-side accumulators (and K/Ka) do not fit in LDS: accumulate dk/dka/dv with global float
 // atomics into the (pre-zeroed) outputs and read K/Ka transposed straight from global memory.
-template <int DH, int NT, bool BIG>
+// ONE = two_level == 0 (layers.py:911-914, 929-936): the origin attention is before_spatial (plain soft-max of the raw
+// scores, its own dropout), and after_spatial enters only through the final mix
+//     A_final = ratio * A_w + (1 - ratio) * after_spatial        (ratio = 0.5, or the trainable parameter).
+// One more tile set (before_spatial) and one more cotangent tile set: built for L <= 64.
+template <int DH, int NT, bool BIG, bool ONE = false>
 __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P, const acattn_bwd_io IO) {
   constexpr int KS = DH / 4;
   constexpr int DT = DH / 16;
@@ -158,6 +162,8 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
   const uint64_t seed_eff = P.seed + (P.seed_device ? *P.seed_device : 0ull);
   const RngKey rkey = rng_key(seed_eff);
   float acc_db_o = 0.f, acc_db_d = 0.f, acc_dsc = 0.f;  // per-lane partials, reduced at the end
+  float acc_drr = 0.f;                                   // d rich_calibrated_combine_ratio (ONE)
+  const float ratio = ONE ? (P.rich_combine == ACATTN_RICH_TRAINABLE ? P.rich_ratio[0] : 0.5f) : 1.0f;
 
   for (int kk = 0;; ++kk) {
     const int qb = (kk & 1) ? (kk + 1) * NW - 1 - wave : kk * NW + wave;
@@ -207,6 +213,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
       st1 = *(const f4*)(sp + 4);
     }
     const float lse_x = st0[0], lse_y = st0[1], lse_u = st0[2], lse_v = st0[3], lse_w = st1[0], lse_f = st1[1];
+    const float lse_b = st1[2];  // before_spatial (written by the forward when two_level == 0)
 
     float mk[NT][4];
 #pragma unroll
@@ -268,11 +275,12 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
     // ---- randomness of this row block (same stream as the forward) ------------------------------------
     float nz[NT][4];
     uint32_t keepA = 0xFFFFFFFFu, keepM = 0xFFFFFFFFu, keepA2 = 0xFFFFFFFFu, keepM2 = 0xFFFFFFFFu;
+    uint32_t keepB = 0xFFFFFFFFu;  // before_spatial's dropout (ONE: NT <= 8)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t < nt) {
         const int j0 = 16 * t + 4 * g;
-        uint32_t ka = 0xFu, km_ = 0xFu;
+        uint32_t ka = 0xFu, km_ = 0xFu, kb_ = 0xFu;
         if (counter) {
           const RngGroup rg = rng_group(rkey, (uint32_t)(bh * L + i), (uint32_t)(4 * t + g), P.p_drop);
 #pragma unroll
@@ -280,6 +288,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
           if (has_drop) {
             ka = rg.keep_after;
             km_ = rg.keep_mask;
+            kb_ = rg.keep_before;
           }
         } else {
 #pragma unroll
@@ -290,9 +299,11 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
             if (has_drop && ok) {
               if (P.keep_after && !P.keep_after[prow + j]) ka &= ~(1u << r);
               if (P.keep_mask && !P.keep_mask[prow + j]) km_ &= ~(1u << r);
+              if (ONE && P.keep_before && !P.keep_before[prow + j]) kb_ &= ~(1u << r);
             }
           }
         }
+        if (ONE && t < 8) keepB = (keepB & ~(0xFu << (4 * t))) | (kb_ << (4 * t));
         if (t < 8) {
           keepA = (keepA & ~(0xFu << (4 * t))) | (ka << (4 * t));
           keepM = (keepM & ~(0xFu << (4 * t))) | (km_ << (4 * t));
@@ -307,6 +318,10 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
     };
     auto scaleA = [&](int t, int r) -> float { return has_drop ? (kept(keepA, keepA2, t, r) ? keep_scale : 0.f) : 1.f; };
     auto scaleM = [&](int t, int r) -> float { return has_drop ? (kept(keepM, keepM2, t, r) ? keep_scale : 0.f) : 1.f; };
+    auto scaleB = [&](int t, int r) -> float { return has_drop ? (((keepB >> (4 * t + r)) & 1u) ? keep_scale : 0.f) : 1.f; };
+    f4 tB[ONE ? NT : 1], dAf[ONE ? NT : 1];  // before_spatial (pre-dropout), cotangent of after_spatial from the final mix
+    // the ORIGIN attention of the adversarial calibrator: after_spatial (two_level) or before_spatial
+    auto porg = [&](int t, int r) -> float { return ONE ? tB[ONE ? t : 0][r] * scaleB(t, r) : tS[t][r] * scaleA(t, r); };
 
     // ---- recompute Pt = softmax(x), Mt = softmax(y) from the saved log-normalisers ---------------------
 #pragma unroll
@@ -318,6 +333,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * t + 4 * g + r;
           float s = tS[t][r];
+          if (ONE) tB[ONE ? t : 0][r] = row_ok ? fast_exp(s * inv_sqrt + mk[t][r] - lse_b) : 0.f;
           if (use_order) {
             const float pr = fast_sigmoid(ao + co4[r]);
             const float val = (j > i) ? pr : 1.0f - pr;
@@ -388,7 +404,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
         if (t < nt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = tS[t][r] * scaleA(t, r), m = tM[t][r] * scaleM(t, r);
+            const float p = porg(t, r), m = tM[t][r] * scaleM(t, r);
             const float u = (p * m + nz[t][r] * (1.0f - m)) + mk[t][r];
             const float a = row_ok ? fast_exp(u - lse_u) : 0.f;
             Ap[t][r] = a;
@@ -404,7 +420,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
         if (t < nt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = tS[t][r] * scaleA(t, r), m = tM[t][r] * scaleM(t, r);
+            const float p = porg(t, r), m = tM[t][r] * scaleM(t, r);
             const float du = Ap[t][r] * (dAp[t][r] - da);
             dPa[t][r] = du * m;
             dMa[t][r] = du * (p - nz[t][r]);
@@ -442,7 +458,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int j = 16 * t + 4 * g + r;
-            const float p = tS[t][r] * scaleA(t, r), m = tM[t][r] * scaleM(t, r);
+            const float p = porg(t, r), m = tM[t][r] * scaleM(t, r);
             const float v_ = p * fast_exp(1.0f - m) + mk[t][r];
             const float ac = row_ok ? fast_exp(v_ - lse_v) : 0.f;
             Ac[t][r] = ac;
@@ -459,6 +475,12 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
             }
             const float aw = row_ok ? fast_exp((ag + mk[t][r]) - lse_w) : 0.f;
             Aw[t][r] = aw;
+            if (ONE) {  // final = ratio * A_w + (1 - ratio) * after_spatial   layers.py:929-934
+              const float dfin = dAw[t][r], a_after = tS[t][r] * scaleA(t, r);
+              acc_drr += dfin * (aw - a_after);
+              dAw[t][r] = ratio * dfin;
+              dAf[ONE ? t : 0][r] = (1.0f - ratio) * dfin;
+            }
             dc += aw * dAw[t][r];
           }
         }
@@ -483,7 +505,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
           f4 dgl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = tS[t][r] * scaleA(t, r);
+            const float p = porg(t, r);
             const float dw = Aw[t][r] * (dAw[t][r] - dc);
             float dp, dac;
             if (P.combine_option == ACATTN_COMBINE_FIXED) {
@@ -532,7 +554,7 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
         if (t < nt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = tS[t][r] * scaleA(t, r), m = tM[t][r] * scaleM(t, r);
+            const float p = porg(t, r), m = tM[t][r] * scaleM(t, r);
             const float ex1 = fast_exp(1.0f - m);
             const float dv = Ac[t][r] * (dAc[t][r] - r1);
             dPa[t][r] += dv * ex1;
@@ -540,7 +562,14 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
           }
         }
       }
-      if (IO.d_ctx_calibrated) key_side(Aw, IO.d_ctx_calibrated, BIG ? IO.dv : aV);  // dv += A_w^T . dctx_c
+      if (ONE) {  // the value gradient sees the FINAL attention (A_w is not read again below)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (t < nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Aw[t][r] = ratio * Aw[t][r] + (1.0f - ratio) * (tS[t][r] * scaleA(t, r));
+      }
+      if (IO.d_ctx_calibrated) key_side(Aw, IO.d_ctx_calibrated, BIG ? IO.dv : aV);  // dv += A_final^T . dctx_c
     }
 
     // ---- external cotangent of M, then back through the two first-level softmaxes ------------------------
@@ -562,21 +591,29 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
         }
       }
     }
-    float r2 = 0.f, r3 = 0.f;
+    float r2 = 0.f, r3 = 0.f, r3b = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t < nt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           dMa[t][r] *= scaleM(t, r);  // d Mt
-          dPa[t][r] *= scaleA(t, r);  // d Pt
           r2 += tM[t][r] * dMa[t][r];
-          r3 += tS[t][r] * dPa[t][r];
+          if (ONE) {
+            dPa[t][r] *= scaleB(t, r);                // d Bt: the origin's cotangent goes to before_spatial
+            dAf[ONE ? t : 0][r] *= scaleA(t, r);      // d Pt: after_spatial only hears the final mix
+            r3b += tB[ONE ? t : 0][r] * dPa[t][r];
+            r3 += tS[t][r] * dAf[ONE ? t : 0][r];
+          } else {
+            dPa[t][r] *= scaleA(t, r);  // d Pt
+            r3 += tS[t][r] * dPa[t][r];
+          }
         }
       }
     }
     r2 = quad_sum(r2);
     r3 = quad_sum(r3);
+    if (ONE) r3b = quad_sum(r3b);
     float da_o = 0.f, da_d = 0.f;
     f4 dco[NT], dcd[NT];
 #pragma unroll
@@ -590,9 +627,11 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * t + 4 * g + r;
           const float dSa = (tM[t][r] * (dMa[t][r] - r2)) * inv_sqrt;
-          const float dS = (tS[t][r] * (dPa[t][r] - r3)) * inv_sqrt;
+          // dS: cotangent of the score as seen through after_spatial (the calibrator terms are additive there)
+          const float dS = (tS[t][r] * ((ONE ? dAf[ONE ? t : 0][r] : dPa[t][r]) - r3)) * inv_sqrt;
           dMa[t][r] = dSa;  // from here on: dSa
-          dPa[t][r] = dS;   //               dS' (= dS: the calibrator terms are additive)
+          // total cotangent of the raw score (ONE: plus the path through before_spatial, which has no calibrator)
+          dPa[t][r] = ONE ? dS + (tB[ONE ? t : 0][r] * (dPa[t][r] - r3b)) * inv_sqrt : dS;
           if (use_order) {
             const float pr = fast_sigmoid(ao + co4[r]);
             const float val = (j > i) ? pr : 1.0f - pr;
@@ -708,11 +747,13 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
     acc_db_o += __shfl_xor(acc_db_o, off);
     acc_db_d += __shfl_xor(acc_db_d, off);
     acc_dsc += __shfl_xor(acc_dsc, off);
+    acc_drr += __shfl_xor(acc_drr, off);
   }
   if (lane == 0) {
     atomicAdd(s_small + 0, acc_db_o);
     atomicAdd(s_small + 1, acc_db_d);
     atomicAdd(s_small + 2, acc_dsc);
+    if (ONE) atomicAdd(s_small + 3, acc_drr);
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < L * (DH / 4); idx += blockDim.x) {
@@ -749,12 +790,13 @@ __global__ void __launch_bounds__(256) acattn_bwd_kernel(const acattn_problem P,
     IO.dw_dist_part[bh * (IO.part_stride ? IO.part_stride : 2 * DH) + d] = wd;
   }
   if (threadIdx.x < 4)
-    IO.dsmall_part[bh * (IO.part_stride ? IO.part_stride : 4) + threadIdx.x] = threadIdx.x < 3 ? s_small[threadIdx.x] : 0.f;
+    IO.dsmall_part[bh * (IO.part_stride ? IO.part_stride : 4) + threadIdx.x] =
+        (threadIdx.x < 3 || (ONE && P.rich_combine == ACATTN_RICH_TRAINABLE)) ? s_small[threadIdx.x] : 0.f;
 }
 
-template <int DH, int NT, bool BIG>
+template <int DH, int NT, bool BIG, bool ONE = false>
 int launch_kernel(const acattn_problem& p, const acattn_bwd_io& io, int NW, size_t lds, hipStream_t stream) {
-  auto kern = acattn_bwd_kernel<DH, NT, BIG>;
+  auto kern = acattn_bwd_kernel<DH, NT, BIG, ONE>;
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -770,6 +812,11 @@ int launch_nt(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stre
   const int LP = nT * 16, SS = 16 * (nT | 1);
   const size_t small = (size_t)(6 * LP + 2 * DH + 8 + NW * 16 * SS) * sizeof(float);
   const size_t lds = small + (size_t)5 * LP * (DH + 4) * sizeof(float);
+  if (!p.two_level) {
+    if constexpr (NT == 4) return launch_kernel<DH, 4, false, true>(p, io, NW, lds, stream);
+    acattn_set_error("backward with two_level = 0 supports L <= 64");
+    return -1;
+  }
   if (lds <= 150 * 1024) return launch_kernel<DH, NT, false>(p, io, NW, lds, stream);
   // long sequences: key-side sums go through global atomics into zeroed outputs
   const size_t bytes = (size_t)p.B * p.L * p.H * sizeof(float);
@@ -814,10 +861,6 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
   }
   const int rc_fast = acattn_launch_bwd_fast(p, io, stream);
   if (rc_fast != -100) return rc_fast;
-  if (!p.two_level) {
-    acattn_set_error("backward supports two_level = 1 only (every shipped reference config)");
-    return -1;
-  }
   switch (p.H / p.n_heads) {
     case 16: return launch_dh<16>(p, io, stream);
     case 32: return launch_dh<32>(p, io, stream);

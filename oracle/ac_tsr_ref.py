@@ -522,7 +522,8 @@ def bert_full_sort_predict(item_seq: Tensor, item_seq_len: Tensor, P: Dict[str, 
 # ----------------------------------------------------------------------------------------------
 def core_from_projected(mq: Tensor, mk: Tensor, mv: Tensor, qa: Tensor, ka: Tensor, gate_logits: Optional[Tensor],
                         mask: Tensor, w_order, b_order, w_dist, b_dist, scalar, cfg: EncoderCfg,
-                        noise: Tensor, keep_after=None, keep_mask=None, keep_before=None, anneal_rate: float = 1.0):
+                        noise: Tensor, keep_after=None, keep_mask=None, keep_before=None, anneal_rate: float = 1.0,
+                        rich_ratio=None):
     """Everything between the projections and the output dense, following layers.py:695-740,
     664-672, 917-936, 677-680 on already-projected tensors.
 
@@ -564,6 +565,8 @@ def core_from_projected(mq: Tensor, mk: Tensor, mv: Tensor, qa: Tensor, ka: Tens
     if not cfg.two_level:
         if cfg.rich_calibrated_combine == "fixed":
             final = (comb + after) / 2
+        elif cfg.rich_calibrated_combine == "trainable":  # :932-934
+            final = rich_ratio * comb + (1 - rich_ratio) * after
         else:
             raise KeyError(cfg.rich_calibrated_combine)
     return dict(ctx_attacked=context_only(attacked, v), ctx_calibrated=context_only(final, v), M=M, after=after,

@@ -80,6 +80,8 @@ def reinit(module, sigma, gen):
                 prm.copy_(1.0 + 0.1 * torch.randn(prm.shape, generator=gen))
             elif name.endswith("scalar") or name.endswith("mask_loss_weight"):
                 pass
+            elif name.endswith("rich_calibrated_combine_ratio"):  # layers.py:874-875 starts it at 0.5: move it off
+                prm.fill_(0.3)
             else:
                 prm.copy_(sigma * torch.randn(prm.shape, generator=gen))
 
@@ -371,6 +373,9 @@ def main():
                      keep="few")
     if want("enc_onelevel"):
         encoder_case("enc_onelevel", **E, combine="gate", two_level=False, rich="fixed", sigma=0.2, seed=6, keep="few")
+    if want("enc_onelevel_trainable"):
+        encoder_case("enc_onelevel_trainable", **E, combine="gate", two_level=False, rich="trainable", sigma=0.2,
+                     seed=12, keep="few")
     if want("enc_anneal"):
         encoder_case("enc_anneal", B=2, L=50, H=64, h=2, inner=256, n_layers=1, combine="annealing", sigma=0.2, seed=7,
                      keep="few")

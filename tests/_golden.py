@@ -10,7 +10,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 ENCODER_CASES = [
     "enc_gate_init", "enc_gate_stress", "enc_gate_h4", "enc_fixed_dist", "enc_fixed_order_bidir", "enc_gate_bidir",
-    "enc_plain", "enc_onelevel", "enc_anneal", "enc_leftpad", "enc_L200_h4", "enc_L200_d64_bidir", "enc_L37_ragged",
+    "enc_plain", "enc_onelevel", "enc_onelevel_trainable", "enc_anneal", "enc_leftpad", "enc_L200_h4", "enc_L200_d64_bidir", "enc_L37_ragged",
 ]
 MODEL_CASES = ["model_eval", "model_eval_stress", "model_train"]
 BERT_CASES = ["bert_gate", "bert_fixed_scores"]

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 BWD_CASES = ["enc_gate_init", "enc_gate_stress", "enc_gate_h4", "enc_fixed_dist", "enc_fixed_order_bidir",
              "enc_gate_bidir", "enc_plain", "enc_anneal", "enc_leftpad", "enc_L37_ragged", "enc_L200_h4",
-             "enc_L200_d64_bidir"]
+             "enc_L200_d64_bidir", "enc_onelevel", "enc_onelevel_trainable"]
 
 
 def _rel(a, b):
@@ -37,6 +37,7 @@ def test_core_backward_matches_oracle_autograd(name, drop):
     shape = noise.shape
     keep_a = torch.empty(shape).bernoulli_(0.5, generator=g) if drop else None
     keep_m = torch.empty(shape).bernoulli_(0.5, generator=g) if drop else None
+    keep_b = torch.empty(shape).bernoulli_(0.5, generator=g) if (drop and not cfg.two_level) else None
     leaves = {"q": mq, "k": mk, "v": mv, "qa": qa, "ka": ka}
     if gl is not None:
         leaves["gl"] = gl
@@ -44,12 +45,12 @@ def test_core_backward_matches_oracle_autograd(name, drop):
     zero = torch.zeros(1, dh2)
     small = {"w_order": P.get("attack_attention.order_affine.weight", zero), "b_order": P.get("attack_attention.order_affine.bias"),
              "w_dist": P.get("attack_attention.distance_affine.weight", zero), "b_dist": P.get("attack_attention.distance_affine.bias"),
-             "scalar": P.get("attack_attention.scalar")}
+             "scalar": P.get("attack_attention.scalar"), "rich_ratio": P.get("rich_calibrated_combine_ratio")}
     leaves.update({k: v for k, v in small.items() if v is not None and (k.startswith("w_") is False or True)})
     cpu = {k: v.detach().clone().requires_grad_(True) for k, v in leaves.items()}
     ref = O.core_from_projected(cpu["q"], cpu["k"], cpu["v"], cpu["qa"], cpu["ka"], cpu.get("gl"), mask, cpu["w_order"],
                                 cpu.get("b_order"), cpu["w_dist"], cpu.get("b_dist"), cpu.get("scalar"), cfg, noise,
-                                keep_after=keep_a, keep_mask=keep_m)
+                                keep_after=keep_a, keep_mask=keep_m, keep_before=keep_b, rich_ratio=cpu.get("rich_ratio"))
     cot = {k: torch.randn(ref[k].shape, generator=g) for k in ("ctx_attacked", "ctx_calibrated", "M")}
     loss = sum((ref[k] * cot[k]).sum() for k in cot)
     names = [k for k in cpu]
@@ -59,8 +60,11 @@ def test_core_backward_matches_oracle_autograd(name, drop):
     acfg = A.AttentionConfig(n_heads=cfg.n_heads, combine_option=cfg.combine_option, two_level=cfg.two_level,
                              rich_calibrated_combine=cfg.rich_calibrated_combine)
     rnd = A.ExplicitRandomness(noise=noise.to(DEV), keep_after=None if keep_a is None else keep_a.to(torch.uint8).to(DEV),
-                               keep_mask=None if keep_m is None else keep_m.to(torch.uint8).to(DEV))
+                               keep_mask=None if keep_m is None else keep_m.to(torch.uint8).to(DEV),
+                               keep_before=None if keep_b is None else keep_b.to(torch.uint8).to(DEV))
     kw = {}
+    if "rich_ratio" in dev:
+        kw.update(rich_ratio=dev["rich_ratio"])
     if cfg.use_order:
         kw.update(w_order=dev["w_order"], b_order=dev["b_order"])
     if cfg.use_distance:

@@ -38,6 +38,8 @@ def _core_kwargs(P, cfg):
     if cfg.use_distance:
         kw.update(w_dist=P["attack_attention.distance_affine.weight"].to(DEV), b_dist=P["attack_attention.distance_affine.bias"].to(DEV),
                   scalar=P["attack_attention.scalar"].to(DEV))
+    if "rich_calibrated_combine_ratio" in P:  # layers.py:874-875
+        kw.update(rich_ratio=P["rich_calibrated_combine_ratio"].to(DEV))
     return kw
 
 
@@ -53,7 +55,7 @@ def _oracle_core(c, cfg, P, mq, mk, mv, qa, ka, gl, mask, noise, **kw):
             mq, mk, mv, qa, ka, gl, mask,
             P.get("attack_attention.order_affine.weight", zero), P.get("attack_attention.order_affine.bias"),
             P.get("attack_attention.distance_affine.weight", zero), P.get("attack_attention.distance_affine.bias"),
-            P.get("attack_attention.scalar"), cfg, noise, **kw)
+            P.get("attack_attention.scalar"), cfg, noise, rich_ratio=P.get("rich_calibrated_combine_ratio"), **kw)
 
 
 @pytest.mark.parametrize("name", ENCODER_CASES)
