@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -70,6 +70,21 @@ class LnProblem(C.Structure):
 LN_BWD_GRID = 512
 
 
+class TailProblem(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("ctx", _f), ("x", _f), ("wd", _f), ("bd", _f),
+                ("g1", _f), ("b1", _f), ("w1", _f), ("bb1", _f), ("w2", _f), ("bb2", _f), ("g2", _f), ("b2", _f),
+                ("eps1", C.c_float), ("eps2", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("keep1", _f),
+                ("keep2", _f), ("seed1", C.c_uint64), ("seed2", C.c_uint64), ("seed_device", _f)]
+
+
+class TailSaved(C.Structure):
+    _fields_ = [("h1", _f), ("st1", _f), ("a", _f), ("act", _f), ("h3", _f), ("st2", _f), ("out", _f)]
+
+
+class TailBwdIO(C.Structure):
+    _fields_ = [("d_out", _f), ("d_ctx", _f), ("d_x", _f), ("d_h1", _f), ("d_h2", _f), ("d_h3", _f), ("dgb_part", _f)]
+
+
 class EmbedProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("n_table_rows", C.c_int64), ("idx", _f),
                 ("table", _f), ("pos", _f), ("gamma", _f), ("beta", _f), ("eps", C.c_float), ("p_drop", C.c_float),
@@ -95,6 +110,11 @@ SYMBOLS = {
     "acattn_dropout_add_layernorm_bwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, _f, _f, _f, C.c_void_p]),
     "acattn_embed_layernorm_fwd": (C.c_int, [C.POINTER(EmbedProblem), _f, _f, C.c_void_p]),
     "acattn_embed_layernorm_bwd": (C.c_int, [C.POINTER(EmbedProblem), _f, _f, C.c_int64, _f, _f, _f, C.c_void_p]),
+    "acattn_layer_tail_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "acattn_layer_tail_fwd": (C.c_int, [C.POINTER(TailProblem), C.POINTER(TailSaved), C.c_void_p]),
+    "acattn_layer_tail_bwd": (C.c_int, [C.POINTER(TailProblem), C.POINTER(TailSaved), C.POINTER(TailBwdIO), C.c_void_p]),
+    "acattn_layer_tail_bwd_partial_rows": (C.c_int32, [C.c_int32]),
+    "acattn_select_layer_tail_blocks": (C.c_int, [C.c_int]),
     "acattn_sum_rows": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "acattn_mask_penalty_fwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_void_p]),
     "acattn_mask_penalty_bwd": (C.c_int, [_f, _f, _f, C.c_int64, _f, C.c_void_p]),

@@ -185,6 +185,43 @@ int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy
   return rc;
 }
 
+static int check_tail(const acattn_tail_problem* p, const acattn_tail_saved* s) {
+  if (!p || !s) return fail("problem and saved must be non-NULL");
+  if (p->rows < 1) return fail("rows must be positive");
+  if (!acattn_tail_supported(p->H, p->I)) return fail("layer tail: (hidden_size, inner_size) must be (64, 256) or (64, 128)");
+  if (!p->ctx || !p->x || !p->wd || !p->bd || !p->g1 || !p->b1 || !p->w1 || !p->bb1 || !p->w2 || !p->bb2 || !p->g2 || !p->b2)
+    return fail("layer tail: inputs and parameters must be non-NULL");
+  if (!(p->p1 >= 0.f && p->p1 < 1.f) || !(p->p2 >= 0.f && p->p2 < 1.f)) return fail("dropout probabilities must be in [0, 1)");
+  if (!s->h1 || !s->st1 || !s->a || !s->h3 || !s->st2) return fail("layer tail: saved tensors must be non-NULL");
+  return 0;
+}
+
+int acattn_layer_tail_supported(int32_t H, int32_t I) { return acattn_tail_supported(H, I) ? 1 : 0; }
+
+int32_t acattn_layer_tail_bwd_partial_rows(int32_t rows) { return acattn_tail_bwd_partial_rows(rows); }
+
+int acattn_select_layer_tail_blocks(int nb) {
+  if (nb < 0 || nb > 2) return fail("rows per wave: 0 (automatic), 1 or 2 blocks of 16");
+  return acattn_select_tail_nb(nb);
+}
+
+int acattn_layer_tail_fwd(const acattn_tail_problem* p, const acattn_tail_saved* saved, void* stream) {
+  if (int rc = check_tail(p, saved)) return rc;
+  if (!saved->act || !saved->out) return fail("layer tail forward: act and out must be non-NULL");
+  const int rc = acattn_launch_tail_fwd(*p, *saved, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_layer_tail_bwd(const acattn_tail_problem* p, const acattn_tail_saved* saved, const acattn_tail_bwd_io* io,
+                          void* stream) {
+  if (int rc = check_tail(p, saved)) return rc;
+  if (!io || !io->d_out) return fail("layer tail backward: d_out must be non-NULL");
+  const int rc = acattn_launch_tail_bwd(*p, *saved, *io, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_t C, void* stream) {
   if (!x || !out) return fail("x and out must be non-NULL");
   if (batch < 1 || R < 1 || C < 1) return fail("batch, R, C must be positive");

@@ -211,6 +211,12 @@ int acattn_launch_ln_bwd(const acattn_ln_problem& p, const float* dy, const floa
                          float* dgb_part, hipStream_t stream);
 int acattn_launch_sum_rows(const float* x, float* out, int batch, int R, int C, hipStream_t stream);
 void acattn_set_error(const char* msg);
+bool acattn_tail_supported(int H, int I);
+int acattn_tail_bwd_partial_rows(int rows);
+int acattn_select_tail_nb(int nb);
+int acattn_launch_tail_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream);
+int acattn_launch_tail_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const acattn_tail_bwd_io& io,
+                           hipStream_t stream);
 int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N);
 int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, const int* K, const int* N,
                                float* const* dw, float* const* db, int n_items, int64_t M, void* ws, hipStream_t stream);

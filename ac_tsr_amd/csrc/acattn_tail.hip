@@ -1,0 +1,490 @@
+// The position-wise tail of one branch of an AC-TSR encoder layer as ONE launch, forward and backward, for gfx950:
+//
+//     a   = LayerNorm(dropout(dense(ctx)) + x)                  cal_adjusted_outputs, recbole/model/layers.py:681-683
+//     out = LayerNorm(dropout(dense_2(gelu(dense_1(a)))) + a)   FeedForward.forward,  layers.py:790-798 (erf-GELU :776-785)
+//
+// Three small GEMMs (H x H, I x H, H x I with H = 64, I = 256: 147 KB of weights), two LayerNorms and a GELU: as
+// separate launches they are six kernels forward and about fifteen backward, each at the launch floor for the
+// 512-row tails of the last layer and each a full HBM round trip of [rows, H] / [rows, I] for the 25,600-row tail
+// of the first.  Here one WAVE owns 16 (or 32) rows for the whole chain and everything stays in registers:
+//
+//   * every product is computed TRANSPOSED, out^T = W . in^T, with the exact-fp32 16x16x4 MFMA: the batch row sits on
+//     the lane index (lane & 15), so a GEMM's accumulator registers are directly the B operand of the next GEMM, the
+//     LayerNorm statistics of a row are 16 register values + one 4-lane reduction, and bias / dropout / residual /
+//     GELU are lane-local;
+//   * the contraction index is visited in the order the previous accumulator happens to hold it (k-step (t, r) =
+//     feature 16t + 4g + r on lane group g), so the weight fragment of an output tile is one 16-byte load per lane:
+//     W[16 nt + c][16 t + 4 g ..+3].  Weights are read from L2 (they are 147 KB and every wave reads all of them);
+//     the next k-slab's fragments are requested before the current slab's MFMAs;
+//   * dense_1 -> GELU -> dense_2 is one loop over the 16-column slabs of the inner dimension: the [16 rows, I]
+//     activation never exists as a whole, each slab is stored (the weight-gradient GEMM needs it) and consumed.
+//
+// Backward (input gradients, LayerNorm parameter partials): the same chain mirrored; the inner activation is
+// REBUILT from `a` (one more H x I product per slab instead of a 26 MB read), the transposed weights are gathered
+// as dwords straight from the row-major parameters (no transposed copies).  The weight/bias gradients stay with
+// acattn_linear_wgrad_grouped, which reads the d_h1 / d_h2 / d_h3 tiles this kernel writes when asked to.
+//
+// Measured (MI355X, rocprofv3, 25,600 rows / 512 rows; profiles/r02_tail_kernels.txt): forward 38.6 / 17.5 us,
+// backward 50.9 / 24.9 us, against 6 + ~15 launches of 275 / 117 us in total per forward + two backward walks.
+// What bounds it: the fp32 MFMAs (576 forward, 784 backward per 16 rows, 32 cycles each) share the issue port with
+// the VALU work between them (GELU, LayerNorm, address arithmetic: about +40 %), and 1,600 row blocks on 1,024 SIMDs
+// leave the critical SIMD with two blocks.  Without the stores 37.5 us, without GELU 34.0, without both 33.7, with the
+// weight fragments always hitting L1 31.4: neither HBM nor L2 is the limit.
+//
+// Dropout decisions: row_keep_scale() of acattn_rowops.h, i.e. exactly those of acattn_ln.hip for the same
+// (seed, row, column): the fused and the unfused formulation are interchangeable between forward and backward.
+#include <algorithm>
+
+#include "acattn_common.h"
+#include "acattn_rowops.h"
+
+int acattn_tail_bwd_partial_rows(int rows);
+
+namespace {
+
+int g_tail_nb = 0;  // rows per wave / 16; 0 = by size (measurement hook: acattn_select_layer_tail_blocks)
+int rows_per_wave(int rows) { return 16 * (g_tail_nb ? g_tail_nb : (rows >= 16384 ? 2 : 1)); }
+
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
+
+// Phi(x) = (1 + erf(x / sqrt 2)) / 2 and exp(-x^2 / 2), branch-free: libm's erff is ~45 instructions with a divergent
+// branch per element, and on this chip VALU work does not hide behind the fp32 MFMAs.  Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute, i.e. at the rounding level of the fp32 result) with the hardware rcp / exp2:
+//     erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z >= 0
+struct PhiExp {
+  float phi, e;  // Phi(x), exp(-x^2 / 2)
+};
+__device__ __forceinline__ PhiExp phi_exp(float x) {
+  const float z = fabsf(x) * kInvSqrt2;
+  const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2/2) = 2^(-x^2 log2(e) / 2)
+  float q = fmaf(t, 1.061405429f, -1.453152027f);
+  q = fmaf(t, q, 1.421413741f);
+  q = fmaf(t, q, -0.284496736f);
+  q = fmaf(t, q, 0.254829592f);
+  const float half_tail = 0.5f * (q * t) * e;  // (1 - erf(z)) / 2
+  return PhiExp{x >= 0.f ? 1.0f - half_tail : half_tail, e};
+}
+__device__ __forceinline__ float gelu_erf(float x) { return x * phi_exp(x).phi; }  // layers.py:776-785
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const PhiExp pe = phi_exp(x);
+  return fmaf(x * kInvSqrt2Pi, pe.e, pe.phi);
+}
+
+template <int NB>
+struct Rows {
+  int row[NB];   // clamped (loads)
+  bool ok[NB];   // row < R (stores)
+};
+
+template <int NB>
+__device__ __forceinline__ Rows<NB> wave_rows(int R) {
+  Rows<NB> w;
+  const int c = threadIdx.x & 15;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int r = (blockIdx.x * NB + nb) * 16 + c;
+    w.ok[nb] = r < R;
+    w.row[nb] = r < R ? r : R - 1;
+  }
+  return w;
+}
+
+// y = LayerNorm(z * keep + res) in the accumulator layout (lane (c, g), tile t, register r <-> row c, feature 16t+4g+r)
+template <int DT>
+__device__ __forceinline__ void ln_forward(const f4 (&z)[DT], const f4 (&res)[DT], const f4 (&keep)[DT], const float* gamma,
+                                           const float* beta, float eps, int g, f4 (&y)[DT], float& mean, float& rstd) {
+  constexpr float inv_h = 1.0f / (16 * DT);
+  f4 s[DT];
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    s[t] = z[t] * keep[t] + res[t];
+    sum += (s[t][0] + s[t][1]) + (s[t][2] + s[t][3]);
+  }
+  mean = quad_sum(sum) * inv_h;
+  float sq = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    s[t] = s[t] - mean;
+    sq += (s[t][0] * s[t][0] + s[t][1] * s[t][1]) + (s[t][2] * s[t][2] + s[t][3] * s[t][3]);
+  }
+  rstd = __builtin_amdgcn_rsqf(quad_sum(sq) * inv_h + eps);
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+    y[t] = (s[t] * rstd) * *(const f4*)(gamma + 16 * t + 4 * g) + *(const f4*)(beta + 16 * t + 4 * g);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// forward
+// -----------------------------------------------------------------------------------------------------------------
+template <int H, int I, int NB>
+__global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
+  constexpr int DT = H / 16, IT = I / 16;
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const Rows<NB> W = wave_rows<NB>(P.rows);
+  const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
+
+  // ---- h1 = dense(ctx) + bias -----------------------------------------------------------------------------------
+  f4 cb[NB][DT];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int t = 0; t < DT; ++t) cb[nb][t] = *(const f4*)(P.ctx + (size_t)W.row[nb] * H + 16 * t + 4 * g);
+  f4 h1[NB][DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt) {
+    const f4 b = *(const f4*)(P.bd + 16 * nt + 4 * g);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) h1[nb][nt] = b;
+  }
+  {
+    f4 wd[DT][DT];
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) wd[nt][t] = *(const f4*)(P.wd + (size_t)(16 * nt + c) * H + 16 * t + 4 * g);
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) h1[nb][nt] = mfma16(wd[nt][t][r], cb[nb][t][r], h1[nb][nt]);
+  }
+
+  // ---- a = LayerNorm(dropout(h1) + x) ---------------------------------------------------------------------------
+  f4 a[NB][DT];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f4 res[DT], keep[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      res[t] = *(const f4*)(P.x + (size_t)W.row[nb] * H + 16 * t + 4 * g);
+      keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, W.row[nb], 4 * t + g, H);
+    }
+    float mean, rstd;
+    ln_forward<DT>(h1[nb], res, keep, P.g1, P.b1, P.eps1, g, a[nb], mean, rstd);
+    if (W.ok[nb]) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
+        *(f4*)(S.h1 + o) = h1[nb][t];
+        *(f4*)(S.a + o) = a[nb][t];
+      }
+      if (g == 0) *(float2*)(S.st1 + 2 * (size_t)W.row[nb]) = float2{mean, rstd};
+    }
+  }
+
+  // ---- h3 = dense_2(gelu(dense_1(a))), one 16-column slab of the inner dimension at a time -----------------------
+  f4 h3[NB][DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt) {
+    const f4 b = *(const f4*)(P.bb2 + 16 * nt + 4 * g);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) h3[nb][nt] = b;
+  }
+  // weight fragments (and the bias) of a slab are requested one slab ahead: nothing the current slab's MFMAs wait for
+  // is younger than the previous iteration's requests (vmcnt retires in order)
+  struct Slab {
+    f4 w1[DT];  // A[m = 16mt+c][k = 16t+4g+r]
+    f4 w2[DT];  // A[n = 16t+c][m = 16mt+4g+r]
+    f4 b1;
+  };
+  auto load_slab = [&](int mt, Slab& s) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      s.w1[t] = *(const f4*)(P.w1 + (size_t)(16 * mt + c) * H + 16 * t + 4 * g);
+      s.w2[t] = *(const f4*)(P.w2 + (size_t)(16 * t + c) * I + 16 * mt + 4 * g);
+    }
+    s.b1 = *(const f4*)(P.bb1 + 16 * mt + 4 * g);
+  };
+  Slab cur, nxt;
+  load_slab(0, cur);
+#pragma unroll 2
+  for (int mt = 0; mt < IT; ++mt) {
+    load_slab(mt + 1 < IT ? mt + 1 : mt, nxt);
+    f4 h2[NB][2];  // two partial accumulators: a dependent 16x16x4 chain issues every 40 cycles, alternating every 32
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) h2[nb][0] = h2[nb][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) h2[nb][r & 1] = mfma16(cur.w1[t][r], a[nb][t][r], h2[nb][r & 1]);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const f4 pre = (h2[nb][0] + h2[nb][1]) + cur.b1;
+      f4 act;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) act[r] = gelu_erf(pre[r]);
+      if (W.ok[nb]) *(f4*)(S.act + (size_t)W.row[nb] * I + 16 * mt + 4 * g) = act;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt) h3[nb][nt] = mfma16(cur.w2[nt][r], act[r], h3[nb][nt]);
+    }
+    cur = nxt;
+  }
+
+  // ---- out = LayerNorm(dropout(h3) + a) -------------------------------------------------------------------------
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f4 keep[DT], y[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) keep[t] = row_keep_scale(P.p2, P.keep2, P.seed2 + step, W.row[nb], 4 * t + g, H);
+    float mean, rstd;
+    ln_forward<DT>(h3[nb], a[nb], keep, P.g2, P.b2, P.eps2, g, y, mean, rstd);
+    if (W.ok[nb]) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
+        *(f4*)(S.h3 + o) = h3[nb][t];
+        *(f4*)(S.out + o) = y[t];
+      }
+      if (g == 0) *(float2*)(S.st2 + 2 * (size_t)W.row[nb]) = float2{mean, rstd};
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// backward
+// -----------------------------------------------------------------------------------------------------------------
+// dz = rstd (g gamma - mean(g gamma) - xhat mean(g gamma xhat)); partial sums of dgamma = g xhat, dbeta = g over the
+// wave's rows go to part[0 .. 2H) (reduced over the 16 row lanes, written by lane c == 0 of every group)
+template <int DT>
+__device__ __forceinline__ void ln_backward(const f4 (&z)[DT], const f4 (&res)[DT], const f4 (&keep)[DT], const float* gamma,
+                                            float mean, float rstd, const f4 (&dy)[DT], bool ok, int g, f4 (&dz)[DT],
+                                            f4 (&acc_g)[DT], f4 (&acc_b)[DT]) {
+  constexpr float inv_h = 1.0f / (16 * DT);
+  f4 xh[DT], gg[DT];
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    xh[t] = ((z[t] * keep[t] + res[t]) - mean) * rstd;
+    gg[t] = dy[t] * *(const f4*)(gamma + 16 * t + 4 * g);
+    m1 += (gg[t][0] + gg[t][1]) + (gg[t][2] + gg[t][3]);
+    m2 += (gg[t][0] * xh[t][0] + gg[t][1] * xh[t][1]) + (gg[t][2] * xh[t][2] + gg[t][3] * xh[t][3]);
+    if (ok) {
+      acc_g[t] += dy[t] * xh[t];
+      acc_b[t] += dy[t];
+    }
+  }
+  m1 = quad_sum(m1) * inv_h;
+  m2 = quad_sum(m2) * inv_h;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) dz[t] = (gg[t] - m1 - xh[t] * m2) * rstd;
+}
+
+template <int DT>
+__device__ __forceinline__ void store_partial(float* part, const f4 (&acc)[DT], int c, int g) {
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    f4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = dpp_row_sum(acc[t][r]);  // over the 16 rows of the lane group
+    if (c == 0) *(f4*)(part + 16 * t + 4 * g) = v;               // every lane of the row holds the sum
+  }
+}
+
+template <int H, int I, int NB>
+__global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
+                                                      const acattn_tail_bwd_io IO) {
+  constexpr int DT = H / 16, IT = I / 16;
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const Rows<NB> W = wave_rows<NB>(P.rows);
+  const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
+  float* part = IO.dgb_part ? IO.dgb_part + (size_t)blockIdx.x * 4 * H : nullptr;
+
+  // ---- through the second LayerNorm: d h3 (after the dropout), d a (residual share) -------------------------------
+  f4 a[NB][DT], dh3[NB][DT], da[NB][DT];
+  {
+    f4 acc_g[DT], acc_b[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) acc_g[t] = acc_b[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      f4 z[DT], keep[DT], dy[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
+        z[t] = *(const f4*)(S.h3 + o);
+        a[nb][t] = *(const f4*)(S.a + o);
+        dy[t] = *(const f4*)(IO.d_out + o);
+        keep[t] = row_keep_scale(P.p2, P.keep2, P.seed2 + step, W.row[nb], 4 * t + g, H);
+      }
+      const float2 st = *(const float2*)(S.st2 + 2 * (size_t)W.row[nb]);
+      ln_backward<DT>(z, a[nb], keep, P.g2, st.x, st.y, dy, W.ok[nb], g, da[nb], acc_g, acc_b);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        dh3[nb][t] = da[nb][t] * keep[t];
+        if (IO.d_h3 && W.ok[nb]) *(f4*)(IO.d_h3 + (size_t)W.row[nb] * H + 16 * t + 4 * g) = dh3[nb][t];
+      }
+    }
+    if (part) {
+      store_partial<DT>(part + 2 * H, acc_g, c, g);
+      store_partial<DT>(part + 3 * H, acc_b, c, g);
+    }
+  }
+
+  // ---- d a += W1^T (gelu'(h2) * (W2^T d h3)), slab by slab; h2 rebuilt from a --------------------------------------
+  struct Slab {
+    f4 w1[DT];    // dense_1 rows of the slab (rebuilds h2):        A[m = 16mt+c][k = 16t+4g+r]
+    f4 w2t[DT];   // dense_2^T: A[m = 16mt+c][n = 16t+4g+r] = W2[n][m]   (dword gathers)
+    f4 w1t[DT];   // dense_1^T: A[k = 16nt+c][m = 16mt+4g+r] = W1[m][k]  (dword gathers)
+    f4 b1;
+  };
+  auto load_slab = [&](int mt, Slab& s) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      s.w1[t] = *(const f4*)(P.w1 + (size_t)(16 * mt + c) * H + 16 * t + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s.w2t[t][r] = P.w2[(size_t)(16 * t + 4 * g + r) * I + 16 * mt + c];
+        s.w1t[t][r] = P.w1[(size_t)(16 * mt + 4 * g + r) * H + 16 * t + c];
+      }
+    }
+    s.b1 = *(const f4*)(P.bb1 + 16 * mt + 4 * g);
+  };
+  Slab cur, nxt;
+  load_slab(0, cur);
+#pragma unroll 2
+  for (int mt = 0; mt < IT; ++mt) {
+    load_slab(mt + 1 < IT ? mt + 1 : mt, nxt);  // one slab ahead (see the forward)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      f4 h2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, dact[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h2[r & 1] = mfma16(cur.w1[t][r], a[nb][t][r], h2[r & 1]);
+          dact[r & 1] = mfma16(cur.w2t[t][r], dh3[nb][t][r], dact[r & 1]);
+        }
+      const f4 pre = (h2[0] + h2[1]) + cur.b1, dac = dact[0] + dact[1];
+      f4 dh2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh2[r] = dac[r] * gelu_erf_grad(pre[r]);
+      if (IO.d_h2 && W.ok[nb]) *(f4*)(IO.d_h2 + (size_t)W.row[nb] * I + 16 * mt + 4 * g) = dh2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt) da[nb][nt] = mfma16(cur.w1t[nt][r], dh2[r], da[nb][nt]);
+    }
+    cur = nxt;
+  }
+
+  // ---- through the first LayerNorm: d h1, d x; then d ctx = d h1 . Wd ---------------------------------------------
+  f4 dh1[NB][DT];
+  {
+    f4 acc_g[DT], acc_b[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) acc_g[t] = acc_b[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      f4 z[DT], res[DT], keep[DT], dz[DT];
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
+        z[t] = *(const f4*)(S.h1 + o);
+        res[t] = *(const f4*)(P.x + o);
+        keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, W.row[nb], 4 * t + g, H);
+      }
+      const float2 st = *(const float2*)(S.st1 + 2 * (size_t)W.row[nb]);
+      ln_backward<DT>(z, res, keep, P.g1, st.x, st.y, da[nb], W.ok[nb], g, dz, acc_g, acc_b);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
+        dh1[nb][t] = dz[t] * keep[t];
+        if (W.ok[nb]) {
+          if (IO.d_x) *(f4*)(IO.d_x + o) = dz[t];
+          if (IO.d_h1) *(f4*)(IO.d_h1 + o) = dh1[nb][t];
+        }
+      }
+    }
+    if (part) {
+      store_partial<DT>(part, acc_g, c, g);
+      store_partial<DT>(part + H, acc_b, c, g);
+    }
+  }
+  if (IO.d_ctx) {
+    f4 dc[NB][DT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) dc[nb][nt] = f4{0.f, 0.f, 0.f, 0.f};
+    f4 wdt[DT][DT];  // dense^T: A[k = 16nt+c][n = 16t+4g+r] = Wd[n][k]
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wdt[nt][t][r] = P.wd[(size_t)(16 * t + 4 * g + r) * H + 16 * nt + c];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) dc[nb][nt] = mfma16(wdt[nt][t][r], dh1[nb][t][r], dc[nb][nt]);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (W.ok[nb])
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt) *(f4*)(IO.d_ctx + (size_t)W.row[nb] * H + 16 * nt + 4 * g) = dc[nb][nt];
+  }
+}
+
+
+template <int H, int I>
+int launch_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
+  const int nb = rows_per_wave(p.rows) / 16;
+  const int blocks = (p.rows + 16 * nb - 1) / (16 * nb);
+  if (nb == 2)
+    hipLaunchKernelGGL((tail_fwd_kernel<H, I, 2>), dim3(blocks), dim3(64), 0, stream, p, s);
+  else
+    hipLaunchKernelGGL((tail_fwd_kernel<H, I, 1>), dim3(blocks), dim3(64), 0, stream, p, s);
+  return (int)hipGetLastError();
+}
+
+template <int H, int I>
+int launch_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const acattn_tail_bwd_io& io, hipStream_t stream) {
+  const int nb = rows_per_wave(p.rows) / 16;
+  const int blocks = acattn_tail_bwd_partial_rows(p.rows);
+  if (nb == 2)
+    hipLaunchKernelGGL((tail_bwd_kernel<H, I, 2>), dim3(blocks), dim3(64), 0, stream, p, s, io);
+  else
+    hipLaunchKernelGGL((tail_bwd_kernel<H, I, 1>), dim3(blocks), dim3(64), 0, stream, p, s, io);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool acattn_tail_supported(int H, int I) { return H == 64 && (I == 256 || I == 128); }
+
+int acattn_tail_bwd_partial_rows(int rows) { return (rows + rows_per_wave(rows) - 1) / rows_per_wave(rows); }
+
+int acattn_select_tail_nb(int nb) {
+  const int prev = g_tail_nb;
+  g_tail_nb = nb;
+  return prev;
+}
+
+int acattn_launch_tail_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
+  if (p.H == 64 && p.I == 256) return launch_fwd<64, 256>(p, s, stream);
+  if (p.H == 64 && p.I == 128) return launch_fwd<64, 128>(p, s, stream);
+  acattn_set_error("layer tail: unsupported (hidden_size, inner_size)");
+  return -1;
+}
+
+int acattn_launch_tail_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const acattn_tail_bwd_io& io,
+                           hipStream_t stream) {
+  if (p.H == 64 && p.I == 256) return launch_bwd<64, 256>(p, s, io, stream);
+  if (p.H == 64 && p.I == 128) return launch_bwd<64, 128>(p, s, io, stream);
+  acattn_set_error("layer tail: unsupported (hidden_size, inner_size)");
+  return -1;
+}

@@ -3,19 +3,104 @@
     a   = LayerNorm(dropout(dense(ctx)) + x)                  cal_adjusted_outputs, recbole/model/layers.py:681-683
     out = LayerNorm(dropout(dense_2(gelu(dense_1(a)))) + a)   FeedForward.forward,  layers.py:790-798
 
-Forward: the same three GEMMs (hipBLASLt), torch's erf-GELU and two fused dropout+residual+LayerNorm launches.
-Backward, written out by hand: the two LayerNorm backward launches, GELU backward, three input-gradient GEMMs of
-which the one that meets the residual stream accumulates in place (beta = 1), ONE grouped launch pair for the three
-weight/bias gradients and ONE reduction for both LayerNorms' (dgamma, dbeta) partials -- instead of six autograd
-nodes with their own reductions and the elementwise adds autograd inserts where `a` fans out.
+`_FusedLayerTail` (hidden 64, inner 256 / 128: the shipped configuration): ONE HIP launch forward
+(acattn_layer_tail_fwd: the three products on the fp32 matrix cores with the chain held in registers, csrc/acattn_tail.hip)
+and, backward, one launch for every input gradient and the LayerNorm partials (acattn_layer_tail_bwd) + the grouped
+weight-gradient launch pair + one reduction of the partials.
+
+`_LayerTail` (other sizes): the same three GEMMs through hipBLASLt, torch's erf-GELU and two fused
+dropout+residual+LayerNorm launches; backward written out by hand: the two LayerNorm backward launches, GELU backward,
+three input-gradient GEMMs of which the one that meets the residual stream accumulates in place (beta = 1), ONE grouped
+launch pair for the three weight/bias gradients and ONE reduction for both LayerNorms' (dgamma, dbeta) partials --
+instead of six autograd nodes with their own reductions and the elementwise adds autograd inserts where `a` fans out.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.nn.functional as F
 
-from . import fused_ln, ops
+from . import _lib, fused_ln, ops
+from .ops import _ptr, _stream
 from .state import state_of
+
+# measurement switch (bench.py --tail unfused): route supported sizes through the unfused node as well
+FUSED_KERNEL = True
+
+
+def _tail_problem(c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_t):
+    p = _lib.TailProblem()
+    H, I = wd.shape[0], w1.shape[0]
+    p.rows, p.H, p.I = c.numel() // H, H, I
+    p.ctx, p.x = _ptr(c), _ptr(x)
+    p.wd, p.bd, p.g1, p.b1 = _ptr(wd), _ptr(bd), _ptr(g1), _ptr(b1)
+    p.w1, p.bb1, p.w2, p.bb2, p.g2, p.b2 = _ptr(w1), _ptr(bb1), _ptr(w2), _ptr(bb2), _ptr(g2), _ptr(b2)
+    p.eps1, p.eps2, p.p1, p.p2 = float(eps1), float(eps2), float(p1), float(p2)
+    p.keep1, p.keep2 = _ptr(k1), _ptr(k2)
+    p.seed1, p.seed2 = seed1 & 0xFFFFFFFFFFFFFFFF, seed2 & 0xFFFFFFFFFFFFFFFF
+    p.seed_device = _ptr(seed_t)
+    return p
+
+
+class _FusedLayerTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1, p2, keep1, keep2, seed1, seed2,
+                seed_tensor, state):
+        ctx.state = state
+        c, x = c.contiguous(), x.contiguous()
+        params = tuple(t.contiguous() for t in (wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2))
+        k1 = None if keep1 is None else keep1.to(torch.uint8).contiguous()
+        k2 = None if keep2 is None else keep2.to(torch.uint8).contiguous()
+        rows, H, I = c.numel() // c.shape[-1], c.shape[-1], w1.shape[0]
+        new = lambda *shape: torch.empty(*shape, device=c.device, dtype=torch.float32)
+        h1, a, h3, out = (torch.empty_like(c) for _ in range(4))
+        st1, st2, act = new(rows, 2), new(rows, 2), new(rows, I)
+        p = _tail_problem(c, x, *params, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_tensor)
+        sv = _lib.TailSaved()
+        sv.h1, sv.st1, sv.a, sv.act, sv.h3, sv.st2, sv.out = (_ptr(t) for t in (h1, st1, a, act, h3, st2, out))
+        _lib.check(_lib.load().acattn_layer_tail_fwd(C.byref(p), C.byref(sv), _stream()), "layer_tail_fwd")
+        empty = c.new_empty(0)
+        ctx.save_for_backward(c, x, h1, st1, a, act, h3, st2, *params, k1 if k1 is not None else empty,
+                              k2 if k2 is not None else empty, seed_tensor if seed_tensor is not None else empty)
+        ctx.args = (eps1, eps2, p1, p2, k1 is not None, k2 is not None, seed1, seed2, seed_tensor is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        c, x, h1, st1, a, act, h3, st2 = ctx.saved_tensors[:8]
+        params = ctx.saved_tensors[8:18]
+        k1, k2, seed_t = ctx.saved_tensors[18:]
+        eps1, eps2, p1, p2, has_k1, has_k2, seed1, seed2, has_seed_t = ctx.args
+        k1, k2, seed_t = (k1 if has_k1 else None), (k2 if has_k2 else None), (seed_t if has_seed_t else None)
+        want_params = not ctx.state.attack_pass_only  # none of these is an attack transform (trainer.py:678-684)
+        need_c, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        lib = _lib.load()
+        rows, H, I = c.numel() // c.shape[-1], c.shape[-1], act.shape[-1]
+        new = lambda *shape: torch.empty(*shape, device=c.device, dtype=torch.float32)
+        d_out = d_out.contiguous()
+        p = _tail_problem(c, x, *params, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_t)
+        sv = _lib.TailSaved()
+        sv.h1, sv.st1, sv.a, sv.act, sv.h3, sv.st2 = (_ptr(t) for t in (h1, st1, a, act, h3, st2))
+        io = _lib.TailBwdIO()
+        d_c = torch.empty_like(c) if need_c else None
+        d_x = torch.empty_like(x) if need_x else None
+        io.d_out, io.d_ctx, io.d_x = _ptr(d_out), _ptr(d_c), _ptr(d_x)
+        d_h1 = d_h2 = d_h3 = part = None
+        if want_params:
+            d_h1, d_h2, d_h3 = new(rows, H), new(rows, I), new(rows, H)
+            part = new(int(lib.acattn_layer_tail_bwd_partial_rows(rows)), 4 * H)
+            io.d_h1, io.d_h2, io.d_h3, io.dgb_part = _ptr(d_h1), _ptr(d_h2), _ptr(d_h3), _ptr(part)
+        _lib.check(lib.acattn_layer_tail_bwd(C.byref(p), C.byref(sv), C.byref(io), _stream()), "layer_tail_bwd")
+        grads = [None] * 10  # wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2
+        if want_params:
+            two = lambda t: t.reshape(-1, t.shape[-1])
+            (gwd, gbd), (gw1, gb1), (gw2, gb2) = ops.linear_wgrad_grouped(
+                [(two(c), d_h1, True), (two(a), d_h2, True), (act, d_h3, True)])
+            gb = ops.sum_rows(part, 0).view(4, H)  # (dgamma1, dbeta1, dgamma2, dbeta2)
+            grads = [gwd, gbd, gb[0], gb[1], gw1, gb1, gw2, gb2, gb[2], gb[3]]
+        return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None, None)
+
 
 
 class _LayerTail(torch.autograd.Function):
@@ -81,7 +166,10 @@ def layer_tail(ctx_layer, input_tensor, att, ffn, keep_out=None, keep_ffn=None):
     seed1 = state.draw_seed() if (p1 > 0 and keep_out is None) else 0
     seed2 = state.draw_seed() if (p2 > 0 and keep_ffn is None) else 0
     seed_t = state.seed_tensor if (keep_out is None and keep_ffn is None) else None
-    return _LayerTail.apply(ctx_layer, input_tensor, att.dense.weight, att.dense.bias, att.LayerNorm.weight,
+    node = _LayerTail
+    if FUSED_KERNEL and _lib.load().acattn_layer_tail_supported(att.dense.out_features, ffn.dense_1.out_features):
+        node = _FusedLayerTail
+    return node.apply(ctx_layer, input_tensor, att.dense.weight, att.dense.bias, att.LayerNorm.weight,
                             att.LayerNorm.bias, ffn.dense_1.weight, ffn.dense_1.bias, ffn.dense_2.weight,
                             ffn.dense_2.bias, ffn.LayerNorm.weight, ffn.LayerNorm.bias, att.LayerNorm.eps,
                             ffn.LayerNorm.eps, p1, p2, keep_out, keep_ffn, seed1, seed2, seed_t, state)

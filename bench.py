@@ -57,6 +57,8 @@ def parse():
                     help="pin the attention forward kernel (acattn_select_forward_kernel); measurements only")
     ap.add_argument("--bwd-kernel", choices=["auto", "stream", "row"], default="auto",
                     help="pin the attention backward kernel (acattn_select_backward_kernel); measurements only")
+    ap.add_argument("--tail", choices=["fused", "unfused"], default="fused",
+                    help="layer tail: the fused launch (acattn_layer_tail_*) or the unfused node; measurements only")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffer, graph without optimizer) even on one GPU")
     a = ap.parse_args()
@@ -242,6 +244,8 @@ def main():
     from ac_tsr_amd import _lib, parallel
     _lib.load().acattn_select_forward_kernel(["auto", "stream", "staged", "general"].index(a.fwd_kernel))
     _lib.load().acattn_select_backward_kernel(["auto", "stream", "row"].index(a.bwd_kernel))
+    from ac_tsr_amd import tail as _tail
+    _tail.FUSED_KERNEL = a.tail == "fused"
 
     if world > 1:
         parallel.init_distributed("nccl")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 16
+#define ACATTN_ABI_VERSION 17
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -248,6 +248,65 @@ int acattn_linear_wgrad(const float* x, const float* dy, int64_t M, int32_t K, i
 int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, const int32_t* K, const int32_t* N,
                                 float* const* dw, float* const* db, int32_t n_items, int64_t M, void* workspace,
                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The position-wise tail of one branch of an encoder layer in one launch (forward) / one launch (input gradients):
+ *     a   = LayerNorm(dropout(dense(ctx)) + x)                  recbole/model/layers.py:681-683 (cal_adjusted_outputs)
+ *     out = LayerNorm(dropout(dense_2(gelu(dense_1(a)))) + a)   recbole/model/layers.py:790-798 (FeedForward, erf-GELU)
+ * Replaces 3 GEMM + 2 dropout/add/LayerNorm + 1 GELU launches.  (H, I) in {(64, 256), (64, 128)}; weights are the
+ * row-major nn.Linear parameters ([out, in]).  Dropout decisions are those of acattn_dropout_add_layernorm_* for
+ * the same (seed, row, column). */
+typedef struct acattn_tail_problem {
+  int32_t rows, H, I;      /* rows = positions (B*L or the selected ones); H hidden_size; I inner_size */
+  const float* ctx;        /* [rows,H] merged-head context (attention output before the dense) */
+  const float* x;          /* [rows,H] the layer's input (residual of the first LayerNorm) */
+  const float* wd;         /* [H,H] attack_attention.dense.weight */
+  const float* bd;         /* [H] */
+  const float* g1;         /* [H] attack_attention.LayerNorm.weight */
+  const float* b1;         /* [H] */
+  const float* w1;         /* [I,H] feed_forward.dense_1.weight */
+  const float* bb1;        /* [I] */
+  const float* w2;         /* [H,I] feed_forward.dense_2.weight */
+  const float* bb2;        /* [H] */
+  const float* g2;         /* [H] feed_forward.LayerNorm.weight */
+  const float* b2;         /* [H] */
+  float eps1, eps2;        /* layer_norm_eps of the two norms */
+  float p1, p2;            /* hidden_dropout_prob of out_dropout / feed_forward.dropout in training, 0 in eval */
+  const uint8_t* keep1;    /* optional explicit keep masks [rows,H]; NULL = counter RNG from (seed, seed_device) */
+  const uint8_t* keep2;
+  uint64_t seed1, seed2;
+  const uint64_t* seed_device;
+} acattn_tail_problem;
+
+/* Tensors the forward writes and the backward reads (all required in both directions, `act` forward only). */
+typedef struct acattn_tail_saved {
+  float* h1;   /* [rows,H] dense(ctx) + bias */
+  float* st1;  /* [rows,2] (mean, 1/std) of the first norm */
+  float* a;    /* [rows,H] output of the first norm */
+  float* act;  /* [rows,I] gelu(dense_1(a)): operand of dense_2's weight gradient */
+  float* h3;   /* [rows,H] dense_2(act) + bias */
+  float* st2;  /* [rows,2] */
+  float* out;  /* [rows,H] the branch's output */
+} acattn_tail_saved;
+
+typedef struct acattn_tail_bwd_io {
+  const float* d_out;  /* [rows,H] */
+  float* d_ctx;        /* [rows,H] or NULL */
+  float* d_x;          /* [rows,H] or NULL */
+  float* d_h1;         /* [rows,H], d_h2 [rows,I], d_h3 [rows,H]: cotangents of the three dense outputs, i.e. the */
+  float* d_h2;         /*   operands of acattn_linear_wgrad_grouped with (ctx, a, act); each may be NULL */
+  float* d_h3;
+  float* dgb_part;     /* [acattn_layer_tail_bwd_partial_rows(rows), 4, H] partial sums of (dgamma1, dbeta1, dgamma2,
+                          dbeta2), to be summed over the leading dimension by the caller; or NULL */
+} acattn_tail_bwd_io;
+
+int acattn_layer_tail_supported(int32_t H, int32_t I);
+int acattn_layer_tail_fwd(const acattn_tail_problem* p, const acattn_tail_saved* saved, void* stream);
+int acattn_layer_tail_bwd(const acattn_tail_problem* p, const acattn_tail_saved* saved, const acattn_tail_bwd_io* io,
+                          void* stream);
+int32_t acattn_layer_tail_bwd_partial_rows(int32_t rows);
+/* Measurement hook: rows per wave of the forward = 16 * nb (0 = chosen by size).  Returns the previous setting. */
+int acattn_select_layer_tail_blocks(int nb);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);
