@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -70,6 +70,21 @@ class LnProblem(C.Structure):
 LN_BWD_GRID = 512
 
 
+class ProjProblem(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("H", C.c_int32), ("G", C.c_int32), ("x", _f), ("wq", _f), ("bq", _f), ("wk", _f),
+                ("bk", _f), ("wv", _f), ("bv", _f), ("waq", _f), ("baq", _f), ("wak", _f), ("bak", _f), ("wg", _f),
+                ("bg", _f)]
+
+
+class ProjOut(C.Structure):
+    _fields_ = [("mq", _f), ("mk", _f), ("mv", _f), ("qa", _f), ("ka", _f), ("gate", _f)]
+
+
+class ProjBwdIO(C.Structure):
+    _fields_ = [("dmq", _f), ("dmk", _f), ("dmv", _f), ("dqa", _f), ("dka", _f), ("dgate", _f), ("dmq_total", _f),
+                ("dmk_total", _f), ("dx", _f)]
+
+
 class TailProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("ctx", _f), ("x", _f), ("wd", _f), ("bd", _f),
                 ("g1", _f), ("b1", _f), ("w1", _f), ("bb1", _f), ("w2", _f), ("bb2", _f), ("g2", _f), ("b2", _f),
@@ -110,6 +125,9 @@ SYMBOLS = {
     "acattn_dropout_add_layernorm_bwd": (C.c_int, [C.POINTER(LnProblem), _f, _f, _f, _f, _f, C.c_void_p]),
     "acattn_embed_layernorm_fwd": (C.c_int, [C.POINTER(EmbedProblem), _f, _f, C.c_void_p]),
     "acattn_embed_layernorm_bwd": (C.c_int, [C.POINTER(EmbedProblem), _f, _f, C.c_int64, _f, _f, _f, C.c_void_p]),
+    "acattn_projections_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "acattn_projections_fwd": (C.c_int, [C.POINTER(ProjProblem), C.POINTER(ProjOut), C.c_void_p]),
+    "acattn_projections_bwd": (C.c_int, [C.POINTER(ProjProblem), C.POINTER(ProjBwdIO), C.c_void_p]),
     "acattn_layer_tail_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "acattn_layer_tail_fwd": (C.c_int, [C.POINTER(TailProblem), C.POINTER(TailSaved), C.c_void_p]),
     "acattn_layer_tail_bwd": (C.c_int, [C.POINTER(TailProblem), C.POINTER(TailSaved), C.POINTER(TailBwdIO), C.c_void_p]),

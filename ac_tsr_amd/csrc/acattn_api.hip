@@ -185,6 +185,37 @@ int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy
   return rc;
 }
 
+static int check_proj(const acattn_proj_problem* p) {
+  if (!p) return fail("problem must be non-NULL");
+  if (p->rows < 1) return fail("rows must be positive");
+  if (!acattn_proj_supported(p->H, p->G)) return fail("projections: hidden_size must be 64 and the gate at most 64 wide");
+  if (!p->x || !p->wq || !p->bq || !p->wk || !p->bk || !p->wv || !p->bv || !p->waq || !p->baq || !p->wak || !p->bak)
+    return fail("projections: input and parameters must be non-NULL");
+  if ((p->wg != nullptr) != (p->bg != nullptr) || (p->wg != nullptr) != (p->G > 0))
+    return fail("projections: gate weight, bias and width go together");
+  return 0;
+}
+
+int acattn_projections_supported(int32_t H, int32_t G) { return acattn_proj_supported(H, G) ? 1 : 0; }
+
+int acattn_projections_fwd(const acattn_proj_problem* p, const acattn_proj_out* out, void* stream) {
+  if (int rc = check_proj(p)) return rc;
+  if (!out || !out->mq || !out->mk || !out->mv || !out->qa || !out->ka) return fail("projections: outputs must be non-NULL");
+  if ((p->wg != nullptr) != (out->gate != nullptr)) return fail("projections: gate output goes with the gate parameters");
+  const int rc = acattn_launch_proj_fwd(*p, *out, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_projections_bwd(const acattn_proj_problem* p, const acattn_proj_bwd_io* io, void* stream) {
+  if (int rc = check_proj(p)) return rc;
+  if (!io) return fail("io must be non-NULL");
+  if (!io->dmq_total && !io->dmk_total && !io->dx) return fail("projections backward: nothing to compute");
+  const int rc = acattn_launch_proj_bwd(*p, *io, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 static int check_tail(const acattn_tail_problem* p, const acattn_tail_saved* s) {
   if (!p || !s) return fail("problem and saved must be non-NULL");
   if (p->rows < 1) return fail("rows must be positive");

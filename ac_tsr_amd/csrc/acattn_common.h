@@ -211,6 +211,9 @@ int acattn_launch_ln_bwd(const acattn_ln_problem& p, const float* dy, const floa
                          float* dgb_part, hipStream_t stream);
 int acattn_launch_sum_rows(const float* x, float* out, int batch, int R, int C, hipStream_t stream);
 void acattn_set_error(const char* msg);
+bool acattn_proj_supported(int H, int G);
+int acattn_launch_proj_fwd(const acattn_proj_problem& p, const acattn_proj_out& o, hipStream_t stream);
+int acattn_launch_proj_bwd(const acattn_proj_problem& p, const acattn_proj_bwd_io& io, hipStream_t stream);
 bool acattn_tail_supported(int H, int I);
 int acattn_tail_bwd_partial_rows(int rows);
 int acattn_select_tail_nb(int nb);

@@ -139,13 +139,107 @@ class _Projections(torch.autograd.Function):
         return (dx, *grads, None, None)
 
 
+# measurement switch (bench.py --projections library): route supported sizes through the hipBLASLt node as well
+FUSED_PROJECTIONS = True
+
+
+class _FusedProjections(torch.autograd.Function):
+    """`_Projections` as ONE HIP launch each way (acattn_projections_fwd / _bwd, csrc/acattn_proj.hip; hidden 64):
+    x is read once, mq / mk stay in registers between the product that makes them and the ones that consume them.
+    The parameter gradients come from the same grouped acattn_linear_wgrad launch pair as in `_Projections`."""
+
+    @staticmethod
+    def _problem(x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg):
+        from . import _lib
+        from .ops import _ptr
+        p = _lib.ProjProblem()
+        p.rows, p.H, p.G = x.numel() // x.shape[-1], x.shape[-1], (wg.shape[0] if wg is not None else 0)
+        p.x = _ptr(x)
+        for name, t in (("wq", wq), ("bq", bq), ("wk", wk), ("bk", bk), ("wv", wv), ("bv", bv), ("waq", waq), ("baq", baq),
+                        ("wak", wak), ("bak", bak), ("wg", wg), ("bg", bg)):
+            setattr(p, name, _ptr(t))
+        return p
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg, attack_upstream, state):
+        import ctypes as C
+        from . import _lib
+        from .ops import _ptr, _stream
+        x = x.contiguous()
+        params = [None if t is None else t.contiguous() for t in (wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg)]
+        p = _FusedProjections._problem(x, *params)
+        mq, mk, mv, qa, ka = (torch.empty_like(x) for _ in range(5))
+        gate = x.new_empty(*x.shape[:-1], p.G) if wg is not None else None
+        out = _lib.ProjOut()
+        out.mq, out.mk, out.mv, out.qa, out.ka, out.gate = (_ptr(t) for t in (mq, mk, mv, qa, ka, gate))
+        _lib.check(_lib.load().acattn_projections_fwd(C.byref(p), C.byref(out), _stream()), "projections_fwd")
+        ctx.save_for_backward(x, mq, mk, *(t if t is not None else x.new_empty(0) for t in params))
+        ctx.has_gate = wg is not None
+        ctx.attack_upstream = attack_upstream
+        ctx.state = state
+        ctx.set_materialize_grads(False)
+        return mq, mk, mv, qa, ka, gate
+
+    @staticmethod
+    def backward(ctx, dmq, dmk, dmv, dqa, dka, dgate):
+        import ctypes as C
+        from . import _lib
+        from .ops import _ptr, _stream, linear_wgrad_grouped
+        x, mq, mk = ctx.saved_tensors[:3]
+        params = [t if t.numel() else None for t in ctx.saved_tensors[3:]]
+        two = lambda t: None if t is None else t.reshape(-1, t.shape[-1])
+        con = lambda t: None if t is None else t.contiguous()
+        dmq, dmk, dmv, dqa, dka, dgate = (con(t) for t in (dmq, dmk, dmv, dqa, dka, dgate))
+        if not ctx.has_gate:
+            dgate = None
+        others = not ctx.state.attack_pass_only  # pass 2 keeps only the attack transforms (trainer.py:678-684)
+        attack = not ctx.state.calibrated_pass_only  # pass 1 has them frozen (trainer.py:672-677)
+        need_dx = ctx.needs_input_grad[0] and (others or ctx.attack_upstream)
+        dx = dmq_t = dmk_t = None
+        if need_dx or others:
+            io = _lib.ProjBwdIO()
+            io.dmq, io.dmk, io.dmv, io.dqa, io.dka, io.dgate = (_ptr(t) for t in (dmq, dmk, dmv, dqa, dka, dgate))
+            # dmq / dmk are the attention node's freshly allocated dq / dk: completing them in place touches nothing
+            # anyone else reads
+            dmq_t = dmq if dmq is not None else torch.empty_like(x)
+            dmk_t = dmk if dmk is not None else torch.empty_like(x)
+            dx = torch.empty_like(x) if need_dx else None
+            io.dmq_total, io.dmk_total, io.dx = _ptr(dmq_t), _ptr(dmk_t), _ptr(dx)
+            p = _FusedProjections._problem(x, *params)
+            _lib.check(_lib.load().acattn_projections_bwd(C.byref(p), C.byref(io), _stream()), "projections_bwd")
+        grads = [None] * 12
+        jobs = []
+
+        def want(slot, inp, g, on):
+            if on and g is not None and (ctx.needs_input_grad[slot] or ctx.needs_input_grad[slot + 1]):
+                jobs.append((slot, two(inp), two(g), ctx.needs_input_grad[slot + 1]))
+
+        want(1, x, dmq_t, others)
+        want(3, x, dmk_t, others)
+        want(5, x, dmv, others)
+        want(7, mq, dqa, attack)
+        want(9, mk, dka, attack)
+        if ctx.has_gate:
+            want(11, mq, dgate, others)
+        if jobs:
+            for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs])):
+                grads[slot - 1], grads[slot] = gw, gb
+        return (dx, *grads, None, None)
+
+
 def projections(x, query, key, value, attack_query, attack_key, gate=None, attack_upstream=True):
     """(mq, mk, mv, qa, ka, gate_logits or None) of one encoder layer; see _Projections.  `attack_upstream=False`
     tells the node that nothing that produced `x` holds attack transforms (the first encoder layer)."""
     if not x.is_cuda or not torch.is_grad_enabled():
         mq, mk, mv = query(x), key(x), value(x)
         return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None)
-    return _Projections.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
+    node = _Projections
+    if FUSED_PROJECTIONS and x.dtype == torch.float32 and all(
+            m.bias is not None for m in (query, key, value, attack_query, attack_key) + ((gate,) if gate is not None else ())):
+        from . import _lib
+        if _lib.load().acattn_projections_supported(x.shape[-1], gate.out_features if gate is not None else 0):
+            node = _FusedProjections
+    return node.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
                               attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
                               gate.weight if gate is not None else None, gate.bias if gate is not None else None,
                               attack_upstream, state_of(query))

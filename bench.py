@@ -59,6 +59,8 @@ def parse():
                     help="pin the attention backward kernel (acattn_select_backward_kernel); measurements only")
     ap.add_argument("--tail", choices=["fused", "unfused"], default="fused",
                     help="layer tail: the fused launch (acattn_layer_tail_*) or the unfused node; measurements only")
+    ap.add_argument("--projections", choices=["fused", "library"], default="fused",
+                    help="the six projections of a layer: one launch (acattn_projections_*) or hipBLASLt GEMMs; measurements only")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffer, graph without optimizer) even on one GPU")
     a = ap.parse_args()
@@ -246,6 +248,8 @@ def main():
     _lib.load().acattn_select_backward_kernel(["auto", "stream", "row"].index(a.bwd_kernel))
     from ac_tsr_amd import tail as _tail
     _tail.FUSED_KERNEL = a.tail == "fused"
+    from ac_tsr_amd import linear as _linear
+    _linear.FUSED_PROJECTIONS = a.projections == "fused"
 
     if world > 1:
         parallel.init_distributed("nccl")

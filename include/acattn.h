@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 17
+#define ACATTN_ABI_VERSION 18
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -307,6 +307,42 @@ int acattn_layer_tail_bwd(const acattn_tail_problem* p, const acattn_tail_saved*
 int32_t acattn_layer_tail_bwd_partial_rows(int32_t rows);
 /* Measurement hook: rows per wave of the forward = 16 * nb (0 = chosen by size).  Returns the previous setting. */
 int acattn_select_layer_tail_blocks(int nb);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The six projections in front of the attention core in one launch (forward) / one launch (input gradients):
+ *     mq, mk, mv = query(x), key(x), value(x)                               recbole/model/layers.py:687-689
+ *     qa, ka     = attack_query_transform(mq), attack_key_transform(mk)     recbole/model/layers.py:658-659
+ *     gate       = gate(mq)  [rows, G], G = seq_length                      recbole/model/layers.py:887
+ * hidden_size 64, G <= 64; weights are the row-major nn.Linear parameters ([out, in]). */
+typedef struct acattn_proj_problem {
+  int32_t rows, H, G;        /* G = 0 and wg = bg = NULL without the gate (combine_option != 'gate') */
+  const float* x;            /* [rows,H] the layer's input */
+  const float *wq, *bq;      /* attack_attention.query */
+  const float *wk, *bk;      /* attack_attention.key */
+  const float *wv, *bv;      /* attack_attention.value */
+  const float *waq, *baq;    /* attack_attention.attack_query_transform */
+  const float *wak, *bak;    /* attack_attention.attack_key_transform */
+  const float *wg, *bg;      /* gate [G,H], [G]; or NULL */
+} acattn_proj_problem;
+
+typedef struct acattn_proj_out {
+  float *mq, *mk, *mv, *qa, *ka; /* [rows,H] each */
+  float* gate;                   /* [rows,G] or NULL */
+} acattn_proj_out;
+
+/* Cotangents in (each may be NULL = zero), gradients out (each may be NULL = not wanted):
+ *   dmq_total = dmq + dqa . Waq + dgate . Wg     (cotangent operand of query's weight gradient; may alias dmq)
+ *   dmk_total = dmk + dka . Wak                  (the same for key; may alias dmk)
+ *   dx        = dmq_total . Wq + dmk_total . Wk + dmv . Wv */
+typedef struct acattn_proj_bwd_io {
+  const float *dmq, *dmk, *dmv, *dqa, *dka; /* [rows,H] */
+  const float* dgate;                       /* [rows,G] */
+  float *dmq_total, *dmk_total, *dx;        /* [rows,H] */
+} acattn_proj_bwd_io;
+
+int acattn_projections_supported(int32_t H, int32_t G);
+int acattn_projections_fwd(const acattn_proj_problem* p, const acattn_proj_out* out, void* stream);
+int acattn_projections_bwd(const acattn_proj_problem* p, const acattn_proj_bwd_io* io, void* stream);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);

@@ -1,0 +1,102 @@
+"""GPU suite (-m gpu): the fused projections (acattn_projections_fwd / _bwd, csrc/acattn_proj.hip)
+
+    mq, mk, mv = query(x), key(x), value(x)                               recbole/model/layers.py:687-689
+    qa, ka     = attack_query_transform(mq), attack_key_transform(mk)     recbole/model/layers.py:658-659
+    gate       = gate(mq)                                                 recbole/model/layers.py:887
+
+against the same six nn.Linear in fp64 on the CPU: outputs, and under the trainer's two backward passes
+(recbole/trainer/trainer.py:672-684) every gradient that pass keeps.
+
+Tolerances: outputs 2e-5 absolute (O(1) values, fp32 products); gradients 2e-4 of the tensor's largest magnitude."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ac_tsr_amd import linear
+from ac_tsr_amd.state import StepState
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+W = ("wq", "bq", "wk", "bk", "wv", "bv", "waq", "baq", "wak", "bak", "wg", "bg")
+OUT = ("mq", "mk", "mv", "qa", "ka", "gate")
+
+
+def _inputs(rows, H, G, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    t = dict(x=r(rows, H))
+    for n in ("q", "k", "v", "aq", "ak"):
+        t["w" + n], t["b" + n] = 0.2 * r(H, H), 0.1 * r(H)
+    if G:
+        t["wg"], t["bg"] = 0.2 * r(G, H), 0.1 * r(G)
+    cot = {k: r(rows, G if k == "gate" else H) for k in OUT if (k != "gate" or G)}
+    return t, cot
+
+
+def _reference(t, G):
+    d = {k: v.double().requires_grad_(True) for k, v in t.items()}
+    mq, mk, mv = F.linear(d["x"], d["wq"], d["bq"]), F.linear(d["x"], d["wk"], d["bk"]), F.linear(d["x"], d["wv"], d["bv"])
+    out = dict(mq=mq, mk=mk, mv=mv, qa=F.linear(mq, d["waq"], d["baq"]), ka=F.linear(mk, d["wak"], d["bak"]))
+    if G:
+        out["gate"] = F.linear(mq, d["wg"], d["bg"])
+    return d, out
+
+
+@pytest.mark.parametrize("rows,G", [(512, 50), (37, 50), (16384 + 21, 50), (100, 0), (64, 64), (48, 37)])
+def test_fused_projections_match_fp64_linears(rows, G):
+    H = 64
+    t, cot = _inputs(rows, H, G, seed=rows + G)
+    d, ref = _reference(t, G)
+    loss = sum((ref[k] * cot[k].double()).sum() for k in cot)
+    names = ["x"] + [n for n in W if n in t]
+    want = dict(zip(names, torch.autograd.grad(loss, [d[n] for n in names])))
+    dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
+    args = [dev.get(n) for n in W]
+    attack_names = ("waq", "baq", "wak", "bak")
+
+    def run(state, attack_upstream=True):
+        outs = linear._FusedProjections.apply(dev["x"], *args, attack_upstream, state)
+        got = dict(zip(OUT, outs))
+        return got, sum((got[k] * cot[k].to(DEV)).sum() for k in cot)
+
+    st = StepState()
+    got, dloss = run(st)
+    for k in cot:
+        assert (got[k].detach().cpu() - ref[k].detach().float()).abs().max() <= 2e-5, k
+
+    def check(gr, keys):
+        for k in keys:
+            err = (gr[k].cpu() - want[k].float()).abs().max().item()
+            assert err <= 2e-4 * want[k].abs().max().item() + 1e-6, (k, err)
+
+    # no pass restriction (a module used on its own): every gradient
+    check(dict(zip(names, torch.autograd.grad(dloss, [dev[n] for n in names]))), names)
+    # pass 1: attack transforms frozen;  pass 2: only the attack transforms (+ the input when something upstream holds one)
+    others = [n for n in names if n not in attack_names]
+    got, dloss = run(st)
+    with st.calibrated_pass():
+        check(dict(zip(others, torch.autograd.grad(dloss, [dev[n] for n in others], retain_graph=True))), others)
+    keep = ["x"] + list(attack_names)
+    with st.attack_pass():
+        check(dict(zip(keep, torch.autograd.grad(dloss, [dev[n] for n in keep]))), keep)
+    # first layer in pass 2: no input gradient is owed, the node returns only the attack transforms' gradients
+    got, dloss = run(st, attack_upstream=False)
+    with st.attack_pass():
+        gr = torch.autograd.grad(dloss, [dev[n] for n in attack_names])
+    check(dict(zip(attack_names, gr)), attack_names)
+
+
+def test_fused_projections_equal_library_node():
+    rows, H, G = 25600, 64, 50
+    t, cot = _inputs(rows, H, G, seed=3)
+    dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
+    names = ["x"] + list(W)
+    res = []
+    for node in (linear._FusedProjections, linear._Projections):
+        outs = node.apply(dev["x"], *(dev[n] for n in W), True, StepState())
+        loss = sum((o * cot[k].to(DEV)).sum() for k, o in zip(OUT, outs))
+        res.append((outs, torch.autograd.grad(loss, [dev[n] for n in names])))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert (a - b).abs().max() <= 2e-5
+    for n, a, b in zip(names, res[0][1], res[1][1]):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, n
