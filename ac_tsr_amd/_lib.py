@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 18
+ABI_VERSION = 20
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -58,7 +58,8 @@ class BwdIO(C.Structure):
 
 
 class CeProblem(C.Structure):
-    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("out", _f), ("table", _f), ("target", _f)]
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("out", _f), ("table", _f), ("target", _f),
+                ("coef_is_scalar", C.c_int32), ("coef_scale", C.c_float)]
 
 
 class LnProblem(C.Structure):
@@ -89,7 +90,8 @@ class TailProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("ctx", _f), ("x", _f), ("wd", _f), ("bd", _f),
                 ("g1", _f), ("b1", _f), ("w1", _f), ("bb1", _f), ("w2", _f), ("bb2", _f), ("g2", _f), ("b2", _f),
                 ("eps1", C.c_float), ("eps2", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("keep1", _f),
-                ("keep2", _f), ("seed1", C.c_uint64), ("seed2", C.c_uint64), ("seed_device", _f)]
+                ("keep2", _f), ("seed1", C.c_uint64), ("seed2", C.c_uint64), ("seed_device", _f), ("src_index", _f),
+                ("src_R", C.c_int32), ("src_L", C.c_int32)]
 
 
 class TailSaved(C.Structure):
@@ -135,6 +137,10 @@ SYMBOLS = {
     "acattn_select_layer_tail_blocks": (C.c_int, [C.c_int]),
     "acattn_sum_rows": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "acattn_mask_penalty_fwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_void_p]),
+    "acattn_mask_penalty_partial": (C.c_int, [_f, C.c_int64, _f, C.c_void_p]),
+    "acattn_attacked_loss_finish": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_int64, C.c_float, _f, _f, C.c_int32,
+                                              C.c_void_p]),
+    "acattn_mask_penalty_bwd_scaled": (C.c_int, [_f, _f, _f, C.c_float, C.c_int64, _f, C.c_void_p]),
     "acattn_mask_penalty_bwd": (C.c_int, [_f, _f, _f, C.c_int64, _f, C.c_void_p]),
     "acattn_linear_wgrad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "acattn_linear_wgrad_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

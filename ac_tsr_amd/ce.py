@@ -108,12 +108,120 @@ class _FullSortCEDir(torch.autograd.Function):
         return d_out, d_table, None, None
 
 
+class _FullSortCEMean(torch.autograd.Function):
+    """mean(_FullSortCE rows) as one node: the cotangent of the mean reaches the backward sweep as a device scalar
+    (acattn_ce_problem.coef_is_scalar / coef_scale = 1/B) instead of being broadcast to a [B] tensor by two more
+    launches."""
+
+    @staticmethod
+    def forward(ctx, out, table, target, state):
+        row_loss = _FullSortCE.forward(ctx, out, table, target, state)
+        return row_loss.mean()
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        out, table, target, lse = ctx.saved_tensors
+        lib = _lib.load()
+        p = _problem(out, table, target)
+        p.coef_is_scalar, p.coef_scale = 1, 1.0 / out.shape[0]
+        ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=out.device)
+        d_out = torch.empty_like(out)
+        want_table = ctx.needs_input_grad[1] and not ctx.state.attack_pass_only
+        d_table = torch.empty_like(table) if want_table else None
+        _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_loss.contiguous()), _ptr(ws), _ptr(d_out),
+                                               _ptr(d_table), _stream()), "full_sort_ce_bwd")
+        return d_out, d_table, None, None
+
+
+class _AttackedLoss(torch.autograd.Function):
+    """final_attacked_loss of ACSASRec.calculate_loss (acsasrec.py:129-137) as one node:
+
+        -CrossEntropyLoss(output @ table^T, target) + weight * mean_l torch.norm(1 - M_l, p=2)
+
+    Forward: the CE sweep that also yields d row_loss / d output (acattn_full_sort_ce_fwd_dir), one partial-sum
+    launch per attack mask and ONE finishing launch for both means, the square roots and the combination (as torch
+    ops: mean, neg, 2 x norm-finish, stack, mean, mul, add).  Backward: d output = direction * d_loss (one product;
+    the -1/B is folded into the saved direction), d M_l = d_loss * weight / n * (M_l - 1) / ||1 - M_l||, one launch
+    per mask.  The table gradient is never taken under the two-pass protocol (recbole/trainer/trainer.py:678-684);
+    a caller that does ask for it gets it from the regular backward sweep."""
+
+    @staticmethod
+    def forward(ctx, out, table, target, weight, state, *masks):
+        ctx.state = state
+        lib = _lib.load()
+        B = out.shape[0]
+        p = _problem(out, table, target)
+        nbytes = lib.acattn_full_sort_ce_workspace_bytes(C.byref(p))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
+        lse = torch.empty(B, device=out.device, dtype=torch.float32)
+        row_loss = torch.empty_like(lse)
+        direction = torch.empty_like(out)
+        rc = lib.acattn_full_sort_ce_fwd_dir(C.byref(p), _ptr(ws), _ptr(lse), _ptr(row_loss), _ptr(direction), _stream())
+        if rc == -100:  # too many rows for the per-workgroup slabs: plain forward, regular backward sweep
+            direction = None
+            _lib.check(lib.acattn_full_sort_ce_fwd(C.byref(p), _ptr(ws), _ptr(lse), _ptr(row_loss), _stream()), "full_sort_ce_fwd")
+        else:
+            _lib.check(rc, "full_sort_ce_fwd_dir")
+        masks = tuple(m.contiguous() for m in masks)
+        part = torch.empty(len(masks), _lib.PENALTY_WS_FLOATS, device=out.device, dtype=torch.float32)
+        for l, m in enumerate(masks):
+            _lib.check(lib.acattn_mask_penalty_partial(_ptr(m), m.numel(), _ptr(part[l]), _stream()), "mask_penalty_partial")
+        res = torch.empty(2 + len(masks), device=out.device, dtype=torch.float32)
+        _lib.check(lib.acattn_attacked_loss_finish(_ptr(row_loss), B, _ptr(part), len(masks), masks[0].numel(), weight,
+                                                   _ptr(res), _ptr(direction), 0 if direction is None else direction.numel(),
+                                                   _stream()), "attacked_loss_finish")
+        ctx.has_dir = direction is not None
+        ctx.save_for_backward(out, table, target, lse, direction if direction is not None else lse, res, *masks)
+        ctx.weight, ctx.ws_bytes = weight, nbytes
+        return res[0]
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        out, table, target, lse, direction, res = ctx.saved_tensors[:6]
+        masks = ctx.saved_tensors[6:]
+        lib = _lib.load()
+        d_loss = d_loss.contiguous()
+        d_table = None
+        want_table = ctx.needs_input_grad[1] and not ctx.state.attack_pass_only
+        if want_table or not ctx.has_dir:
+            p = _problem(out, table, target)
+            p.coef_is_scalar, p.coef_scale = 1, -1.0 / out.shape[0]
+            ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=out.device)
+            d_out, d_table = torch.empty_like(out), (torch.empty_like(table) if want_table else None)
+            _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_loss), _ptr(ws), _ptr(d_out), _ptr(d_table),
+                                                   _stream()), "full_sort_ce_bwd")
+        else:
+            d_out = direction * d_loss  # direction already carries -1/B
+        d_masks = []
+        for l, m in enumerate(masks):
+            if not ctx.needs_input_grad[5 + l]:
+                d_masks.append(None)
+                continue
+            d_m = torch.empty_like(m)
+            _lib.check(lib.acattn_mask_penalty_bwd_scaled(_ptr(m), _ptr(res[2 + l]), _ptr(d_loss), ctx.weight / len(masks),
+                                                          m.numel(), _ptr(d_m), _stream()), "mask_penalty_bwd_scaled")
+            d_masks.append(d_m)
+        return (d_out, d_table, None, None, None, *d_masks)
+
+
+def attacked_loss(output: torch.Tensor, table: torch.Tensor, target: torch.Tensor, masks, weight: float,
+                  state=_DEFAULT_STATE):
+    """-CE(output @ table^T, target) + weight * mean_l ||1 - M_l||_2 (acsasrec.py:129-137) as one autograd node, or None
+    when the fused form does not apply (no mask, masks of different sizes)."""
+    masks = [m for m in masks if m is not None]
+    if not masks or any(m.numel() != masks[0].numel() or m.dtype != torch.float32 or not m.is_cuda for m in masks):
+        return None
+    _need_cuda("target", target, torch.int64)
+    return _AttackedLoss.apply(output.contiguous(), table, target, float(weight), state, *masks)
+
+
 def full_sort_cross_entropy(output: torch.Tensor, table: torch.Tensor, target: torch.Tensor,
                             table_grad: bool = True, state=_DEFAULT_STATE) -> torch.Tensor:
     """mean_b [ logsumexp_n(output_b . table_n) - output_b . table_target(b) ].  `table_grad=False` declares that the
     table's gradient of this loss will not be taken (see _FullSortCEDir): same values, cheaper backward."""
-    fn = _FullSortCE if table_grad else _FullSortCEDir
-    return fn.apply(output.contiguous(), table, target, state).mean()
+    if table_grad:
+        return _FullSortCEMean.apply(output.contiguous(), table, target, state)
+    return _FullSortCEDir.apply(output.contiguous(), table, target, state).mean()
 
 
 def full_sort_cross_entropy_rows(output: torch.Tensor, table: torch.Tensor, target: torch.Tensor,

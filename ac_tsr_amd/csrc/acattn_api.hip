@@ -21,7 +21,7 @@ int check_problem(const acattn_problem* p) {
   if (p->H % p->n_heads != 0)
     return fail("The hidden size is not a multiple of the number of attention heads");  // layers.py:618-622
   const int dh = p->H / p->n_heads;
-  if (dh != 16 && dh != 32 && dh != 64) return fail("unsupported head size: dh must be 16, 32 or 64");
+  if (dh != 16 && dh != 32 && dh != 64 && dh != 128) return fail("unsupported head size: dh must be 16, 32, 64 or 128");
   if (p->L > 208) return fail("unsupported sequence length: L must be <= 208");
   if (!p->q || !p->k || !p->v) return fail("q, k, v must be non-NULL");
   if (p->mask_mode == ACATTN_MASK_STRUCTURED) {
@@ -224,6 +224,7 @@ static int check_tail(const acattn_tail_problem* p, const acattn_tail_saved* s) 
     return fail("layer tail: inputs and parameters must be non-NULL");
   if (!(p->p1 >= 0.f && p->p1 < 1.f) || !(p->p2 >= 0.f && p->p2 < 1.f)) return fail("dropout probabilities must be in [0, 1)");
   if (!s->h1 || !s->st1 || !s->a || !s->h3 || !s->st2) return fail("layer tail: saved tensors must be non-NULL");
+  if (p->src_index && (p->src_R < 1 || p->src_L < 1)) return fail("layer tail: src_index needs src_R, src_L >= 1");
   return 0;
 }
 
@@ -302,6 +303,36 @@ int acattn_mask_penalty_bwd(const float* m, const float* norm, const float* d_no
   if (n < 1) return fail("n must be positive");
   if ((((uintptr_t)m | (uintptr_t)d_m) & 15) != 0) return fail("m and d_m must be 16-byte aligned");
   const int rc = acattn_launch_penalty_bwd(m, norm, d_norm, n, d_m, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_mask_penalty_partial(const float* m, int64_t n, float* part, void* stream) {
+  if (!m || !part) return fail("m and part must be non-NULL");
+  if (n < 1) return fail("n must be positive");
+  if (((uintptr_t)m & 15) != 0) return fail("m must be 16-byte aligned");
+  const int rc = acattn_launch_penalty_partial(m, n, part, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_attacked_loss_finish(const float* row_loss, int32_t B, const float* part, int32_t n_masks, int64_t mask_numel,
+                                float weight, float* out, float* scale_buf, int32_t n_scale, void* stream) {
+  if (!row_loss || !part || !out) return fail("row_loss, part and out must be non-NULL");
+  if (B < 1 || n_masks < 1 || mask_numel < 1) return fail("B, n_masks and mask_numel must be positive");
+  if (n_scale < 0 || (n_scale > 0 && !scale_buf)) return fail("scale_buf must be given with n_scale > 0");
+  const int rc = acattn_launch_attacked_loss_finish(row_loss, B, part, n_masks, mask_numel, weight, out, scale_buf, n_scale,
+                                                    (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_mask_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n, float* d_m,
+                                   void* stream) {
+  if (!m || !norm || !d_loss || !d_m) return fail("m, norm, d_loss and d_m must be non-NULL");
+  if (n < 1) return fail("n must be positive");
+  if ((((uintptr_t)m | (uintptr_t)d_m) & 15) != 0) return fail("m and d_m must be 16-byte aligned");
+  const int rc = acattn_launch_penalty_bwd_scaled(m, norm, d_loss, scale, n, d_m, (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;
 }

@@ -865,6 +865,7 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
     case 16: return launch_dh<16>(p, io, stream);
     case 32: return launch_dh<32>(p, io, stream);
     case 64: return launch_dh<64>(p, io, stream);
+    case 128: return launch_dh<128>(p, io, stream);
   }
   return -1;
 }

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
     const int row = 16 * rb + c;
     const bool ok = row < B;
     lse_next = (ok && !DIR) ? lse[row] : 0.f;
-    cf_next = (ok && !DIR) ? coef[row] : 0.f;
+    cf_next = (ok && !DIR) ? coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f) : 0.f;
     tgt_next = ok ? (int)P.target[row] : -1;
   };
   prefetch(0);

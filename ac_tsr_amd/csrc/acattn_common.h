@@ -227,5 +227,10 @@ int acattn_launch_embed_fwd(const acattn_embed_problem& p, float* y, float* stat
 int acattn_launch_embed_bwd(const acattn_embed_problem& p, const float* dy, const float* stats, int64_t padding_idx,
                             float* d_table, float* d_pos_part, float* dgb_part, hipStream_t stream);
 int acattn_launch_penalty_fwd(const float* m, int64_t n, float* ws, float* norm, hipStream_t stream);
+int acattn_launch_penalty_partial(const float* m, int64_t n, float* part, hipStream_t stream);
+int acattn_launch_attacked_loss_finish(const float* row_loss, int B, const float* part, int n_masks, int64_t mask_numel,
+                                       float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream);
+int acattn_launch_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n,
+                                     float* d_m, hipStream_t stream);
 int acattn_launch_penalty_bwd(const float* m, const float* norm, const float* d_norm, int64_t n, float* d_m,
                               hipStream_t stream);

@@ -736,17 +736,22 @@ int launch_nt(const acattn_problem& p, const acattn_fwd_out& o, bool full, hipSt
   const dim3 grid(p.B * p.n_heads), block(64 * NW);
   const bool fast = p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order && p.w_dist &&
                     (!p.adversarial || (p.combine_option == ACATTN_COMBINE_GATE && p.two_level));
+  auto launch = [&](auto kern) {
+    // head size 128 at L > 96 needs more than the default 64 KB of dynamic LDS
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p, o);
+  };
   if (!p.adversarial) {
     if (fast)
-      hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, false, false, true>), grid, block, lds, stream, p, o);
+      launch(acattn_fwd_kernel<DH, NT, false, false, true>);
     else
-      hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, false, false, false>), grid, block, lds, stream, p, o);
+      launch(acattn_fwd_kernel<DH, NT, false, false, false>);
   } else if (full) {
-    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, true, true, false>), grid, block, lds, stream, p, o);
+    launch(acattn_fwd_kernel<DH, NT, true, true, false>);
   } else if (fast) {
-    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, true, false, true>), grid, block, lds, stream, p, o);
+    launch(acattn_fwd_kernel<DH, NT, true, false, true>);
   } else {
-    hipLaunchKernelGGL((acattn_fwd_kernel<DH, NT, true, false, false>), grid, block, lds, stream, p, o);
+    launch(acattn_fwd_kernel<DH, NT, true, false, false>);
   }
   return (int)hipGetLastError();
 }
@@ -797,6 +802,7 @@ int acattn_launch_fwd(const acattn_problem& p, const acattn_fwd_out& o, hipStrea
     case 16: return launch_dh<16>(p, o, full, stream);
     case 32: return launch_dh<32>(p, o, full, stream);
     case 64: return launch_dh<64>(p, o, full, stream);
+    case 128: return launch_dh<128>(p, o, full, stream);
   }
   return -1;
 }

@@ -74,19 +74,23 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 
 template <int NB>
 struct Rows {
-  int row[NB];   // clamped (loads)
-  bool ok[NB];   // row < R (stores)
+  int row[NB];      // clamped (loads)
+  int64_t src[NB];  // row of ctx / x (and of d_ctx / d_x) this tail row reads: == row without a source index
+  bool ok[NB];      // row < R (stores)
 };
 
 template <int NB>
-__device__ __forceinline__ Rows<NB> wave_rows(int R) {
+__device__ __forceinline__ Rows<NB> wave_rows(const acattn_tail_problem& P) {
   Rows<NB> w;
-  const int c = threadIdx.x & 15;
+  const int c = threadIdx.x & 15, R = P.rows;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int r = (blockIdx.x * NB + nb) * 16 + c;
     w.ok[nb] = r < R;
     w.row[nb] = r < R ? r : R - 1;
+    // gather and tail commute (the tail is position-wise): the positions the model reads are picked here instead of
+    // by a gather launch per tensor in front of the tail (and a scatter launch per gradient behind it)
+    w.src[nb] = P.src_index ? (int64_t)(w.row[nb] / P.src_R) * P.src_L + P.src_index[w.row[nb]] : w.row[nb];
   }
   return w;
 }
@@ -123,7 +127,7 @@ template <int H, int I, int NB>
 __global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
   constexpr int DT = H / 16, IT = I / 16;
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const Rows<NB> W = wave_rows<NB>(P.rows);
+  const Rows<NB> W = wave_rows<NB>(P);
   const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
 
   // ---- h1 = dense(ctx) + bias -----------------------------------------------------------------------------------
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem 
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int t = 0; t < DT; ++t) cb[nb][t] = *(const f4*)(P.ctx + (size_t)W.row[nb] * H + 16 * t + 4 * g);
+    for (int t = 0; t < DT; ++t) cb[nb][t] = *(const f4*)(P.ctx + (size_t)W.src[nb] * H + 16 * t + 4 * g);
   f4 h1[NB][DT];
 #pragma unroll
   for (int nt = 0; nt < DT; ++nt) {
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem 
     f4 res[DT], keep[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
-      res[t] = *(const f4*)(P.x + (size_t)W.row[nb] * H + 16 * t + 4 * g);
+      res[t] = *(const f4*)(P.x + (size_t)W.src[nb] * H + 16 * t + 4 * g);
       keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, W.row[nb], 4 * t + g, H);
     }
     float mean, rstd;
@@ -290,12 +294,23 @@ __device__ __forceinline__ void store_partial(float* part, const f4 (&acc)[DT], 
   }
 }
 
+// a selected position may be picked more than once (AcBERT4Rec pads its masked_index with position 0,
+// acbert4rec.py:130-140): with a row selection the (zero-filled) gradient rows are accumulated
+__device__ __forceinline__ void store_grad(float* dst, f4 v, bool accumulate) {
+  if (accumulate) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
+  } else {
+    *(f4*)dst = v;
+  }
+}
+
 template <int H, int I, int NB>
 __global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
                                                       const acattn_tail_bwd_io IO) {
   constexpr int DT = H / 16, IT = I / 16;
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const Rows<NB> W = wave_rows<NB>(P.rows);
+  const Rows<NB> W = wave_rows<NB>(P);
   const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
   float* part = IO.dgb_part ? IO.dgb_part + (size_t)blockIdx.x * 4 * H : nullptr;
 
@@ -390,7 +405,7 @@ __global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem 
       for (int t = 0; t < DT; ++t) {
         const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
         z[t] = *(const f4*)(S.h1 + o);
-        res[t] = *(const f4*)(P.x + o);
+        res[t] = *(const f4*)(P.x + (size_t)W.src[nb] * H + 16 * t + 4 * g);
         keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, W.row[nb], 4 * t + g, H);
       }
       const float2 st = *(const float2*)(S.st1 + 2 * (size_t)W.row[nb]);
@@ -400,7 +415,7 @@ __global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem 
         const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
         dh1[nb][t] = dz[t] * keep[t];
         if (W.ok[nb]) {
-          if (IO.d_x) *(f4*)(IO.d_x + o) = dz[t];
+          if (IO.d_x) store_grad(IO.d_x + (size_t)W.src[nb] * H + 16 * t + 4 * g, dz[t], P.src_index != nullptr);
           if (IO.d_h1) *(f4*)(IO.d_h1 + o) = dh1[nb][t];
         }
       }
@@ -435,7 +450,7 @@ __global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem 
     for (int nb = 0; nb < NB; ++nb)
       if (W.ok[nb])
 #pragma unroll
-        for (int nt = 0; nt < DT; ++nt) *(f4*)(IO.d_ctx + (size_t)W.row[nb] * H + 16 * nt + 4 * g) = dc[nb][nt];
+        for (int nt = 0; nt < DT; ++nt) store_grad(IO.d_ctx + (size_t)W.src[nb] * H + 16 * nt + 4 * g, dc[nb][nt], P.src_index != nullptr);
   }
 }
 

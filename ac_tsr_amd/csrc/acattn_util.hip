@@ -106,6 +106,66 @@ __global__ void __launch_bounds__(256) penalty_bwd_kernel(const float* __restric
   }
 }
 
+// The attacked loss assembled by ONE workgroup (acsasrec.py:129-137):
+//     loss = -mean_b row_loss_b + weight * mean_l sqrt(sum part[l][:])
+// out[0] = loss, out[1] = mean row loss, out[2 + l] = ||1 - M_l||.  `scale_buf` (the CE direction, [n_scale] floats) is
+// multiplied by -1/B by the launch's other workgroups so that the backward of the cross-entropy term is one product with d loss.
+__global__ void __launch_bounds__(256) attacked_loss_finish_kernel(const float* __restrict__ row_loss, const int B,
+                                                                   const float* __restrict__ part, const int n_masks,
+                                                                   const int n_part, const int part_stride,
+                                                                   const float weight, float* __restrict__ out,
+                                                                   float* __restrict__ scale_buf, const int n_scale) {
+  const float k = -1.0f / (float)B;
+  if (blockIdx.x > 0) {  // workgroups 1.. scale the direction, workgroup 0 assembles the loss
+    for (int i = (blockIdx.x - 1) * 256 + threadIdx.x; i < n_scale / 4; i += (gridDim.x - 1) * 256)
+      *(f4*)(scale_buf + 4 * i) = *(const f4*)(scale_buf + 4 * i) * k;
+    if (blockIdx.x == 1 && threadIdx.x < (n_scale & 3)) scale_buf[(n_scale & ~3) + threadIdx.x] *= k;
+    return;
+  }
+  __shared__ float red[256];
+  auto block_sum = [&](float v) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) acc += row_loss[i];
+  const float ce = block_sum(acc) / (float)B;
+  float pen = 0.f;
+  for (int l = 0; l < n_masks; ++l) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 256) a += part[(size_t)l * part_stride + i];
+    const float nv = sqrtf(block_sum(a));
+    if (threadIdx.x == 0) out[2 + l] = nv;
+    pen += nv;
+  }
+  if (threadIdx.x == 0) {
+    out[0] = weight * (pen / (float)n_masks) - ce;
+    out[1] = ce;
+  }
+}
+
+// d_m = d_loss * scale * (m - 1) / norm
+__global__ void __launch_bounds__(256) penalty_bwd_scaled_kernel(const float* __restrict__ m, const float* __restrict__ norm,
+                                                                 const float* __restrict__ d_loss, const float scale,
+                                                                 const int64_t n, float* __restrict__ d_m) {
+  const float nv = norm[0];
+  const float k = nv > 0.f ? d_loss[0] * scale / nv : 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    *(f4*)(d_m + 4 * i) = (*(const f4*)(m + 4 * i) - 1.0f) * k;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t j = (n4 << 2) + threadIdx.x;
+    d_m[j] = (m[j] - 1.0f) * k;
+  }
+}
+
 }  // namespace
 
 int64_t acattn_penalty_ws_floats() { return kPenaltyGrid; }
@@ -114,6 +174,28 @@ int acattn_launch_penalty_fwd(const float* m, int64_t n, float* ws, float* norm,
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, kPenaltyGrid));
   hipLaunchKernelGGL(penalty_partial_kernel, dim3(grid), dim3(256), 0, stream, m, n, ws);
   hipLaunchKernelGGL(penalty_finish_kernel, dim3(1), dim3(256), 0, stream, ws, grid, norm);
+  return (int)hipGetLastError();
+}
+
+static int penalty_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, kPenaltyGrid)); }
+
+int acattn_launch_penalty_partial(const float* m, int64_t n, float* part, hipStream_t stream) {
+  hipLaunchKernelGGL(penalty_partial_kernel, dim3(penalty_grid(n)), dim3(256), 0, stream, m, n, part);
+  return (int)hipGetLastError();
+}
+
+int acattn_launch_attacked_loss_finish(const float* row_loss, int B, const float* part, int n_masks, int64_t mask_numel,
+                                       float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream) {
+  const int scale_wgs = n_scale > 0 ? std::min((n_scale / 4 + 255) / 256 + 1, 64) : 0;
+  hipLaunchKernelGGL(attacked_loss_finish_kernel, dim3(1 + scale_wgs), dim3(256), 0, stream, row_loss, B, part, n_masks,
+                     penalty_grid(mask_numel), kPenaltyGrid, weight, out, scale_buf, n_scale);
+  return (int)hipGetLastError();
+}
+
+int acattn_launch_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n,
+                                     float* d_m, hipStream_t stream) {
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 2048));
+  hipLaunchKernelGGL(penalty_bwd_scaled_kernel, dim3(grid), dim3(256), 0, stream, m, norm, d_loss, scale, n, d_m);
   return (int)hipGetLastError();
 }
 

@@ -199,6 +199,13 @@ class ACSASRec(SequentialRecommender):
                                                                             _rnds=_rnds, _keep_emb=_keep_emb)
         final_attacked_loss = None
         if attacked_output is not None:
+            if (self.loss_type == 'CE' and not self.trainable_mask_loss_weight and attacked_output.is_cuda
+                    and ce.supported(self.hidden_size) and torch.is_grad_enabled()):
+                # the whole expression below as one node (CE sweep with its direction, one finishing launch)
+                final_attacked_loss = ce.attacked_loss(attacked_output, self.item_embedding.weight,
+                                                       interaction[self.POS_ITEM_ID], all_attack_masks,
+                                                       self.mask_loss_weight, self.step_state)
+        if attacked_output is not None and final_attacked_loss is None:
             attacked_loss = -self._cal_loss(attacked_output, interaction, attack_loss=True)
             mask_penalty = [_penalty(m) for m in all_attack_masks if m is not None]
             assert len(mask_penalty) > 0

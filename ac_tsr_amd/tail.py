@@ -29,10 +29,13 @@ from .state import state_of
 FUSED_KERNEL = True
 
 
-def _tail_problem(c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_t):
+def _tail_problem(c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_t,
+                  rows=None):
     p = _lib.TailProblem()
     H, I = wd.shape[0], w1.shape[0]
     p.rows, p.H, p.I = c.numel() // H, H, I
+    if rows is not None:  # [B, R] positions picked out of c / x [B, L, H]
+        p.rows, p.src_index, p.src_R, p.src_L = rows.numel(), _ptr(rows), rows.shape[-1], c.shape[-2]
     p.ctx, p.x = _ptr(c), _ptr(x)
     p.wd, p.bd, p.g1, p.b1 = _ptr(wd), _ptr(bd), _ptr(g1), _ptr(b1)
     p.w1, p.bb1, p.w2, p.bb2, p.g2, p.b2 = _ptr(w1), _ptr(bb1), _ptr(w2), _ptr(bb2), _ptr(g2), _ptr(b2)
@@ -46,45 +49,61 @@ def _tail_problem(c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1
 class _FusedLayerTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1, p2, keep1, keep2, seed1, seed2,
-                seed_tensor, state):
+                seed_tensor, state, pick=None):
+        """`pick` ([B, R] int64 positions): the tail runs on those positions of c / x ([B, L, H]) only and returns
+        [B, R, H]; explicit keep masks are then [B, R, H] as well."""
         ctx.state = state
         c, x = c.contiguous(), x.contiguous()
         params = tuple(t.contiguous() for t in (wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2))
         k1 = None if keep1 is None else keep1.to(torch.uint8).contiguous()
         k2 = None if keep2 is None else keep2.to(torch.uint8).contiguous()
-        rows, H, I = c.numel() // c.shape[-1], c.shape[-1], w1.shape[0]
+        H, I = c.shape[-1], w1.shape[0]
+        if pick is not None:
+            pick = pick.contiguous()
+            assert c.dim() == 3 and x.shape == c.shape and pick.dtype == torch.int64 and pick.shape[0] == c.shape[0]
+            out_shape = (*pick.shape, H)
+        else:
+            out_shape = c.shape
+        rows = 1
+        for d in out_shape[:-1]:
+            rows *= d
         new = lambda *shape: torch.empty(*shape, device=c.device, dtype=torch.float32)
-        h1, a, h3, out = (torch.empty_like(c) for _ in range(4))
+        h1, a, h3, out = (new(*out_shape) for _ in range(4))
         st1, st2, act = new(rows, 2), new(rows, 2), new(rows, I)
-        p = _tail_problem(c, x, *params, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_tensor)
+        p = _tail_problem(c, x, *params, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_tensor, pick)
         sv = _lib.TailSaved()
         sv.h1, sv.st1, sv.a, sv.act, sv.h3, sv.st2, sv.out = (_ptr(t) for t in (h1, st1, a, act, h3, st2, out))
         _lib.check(_lib.load().acattn_layer_tail_fwd(C.byref(p), C.byref(sv), _stream()), "layer_tail_fwd")
         empty = c.new_empty(0)
         ctx.save_for_backward(c, x, h1, st1, a, act, h3, st2, *params, k1 if k1 is not None else empty,
-                              k2 if k2 is not None else empty, seed_tensor if seed_tensor is not None else empty)
-        ctx.args = (eps1, eps2, p1, p2, k1 is not None, k2 is not None, seed1, seed2, seed_tensor is not None)
+                              k2 if k2 is not None else empty, seed_tensor if seed_tensor is not None else empty,
+                              pick if pick is not None else empty)
+        ctx.args = (eps1, eps2, p1, p2, k1 is not None, k2 is not None, seed1, seed2, seed_tensor is not None,
+                    pick is not None)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         c, x, h1, st1, a, act, h3, st2 = ctx.saved_tensors[:8]
         params = ctx.saved_tensors[8:18]
-        k1, k2, seed_t = ctx.saved_tensors[18:]
-        eps1, eps2, p1, p2, has_k1, has_k2, seed1, seed2, has_seed_t = ctx.args
+        k1, k2, seed_t, pick = ctx.saved_tensors[18:]
+        eps1, eps2, p1, p2, has_k1, has_k2, seed1, seed2, has_seed_t, has_pick = ctx.args
         k1, k2, seed_t = (k1 if has_k1 else None), (k2 if has_k2 else None), (seed_t if has_seed_t else None)
+        pick = pick if has_pick else None
         want_params = not ctx.state.attack_pass_only  # none of these is an attack transform (trainer.py:678-684)
         need_c, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         lib = _lib.load()
-        rows, H, I = c.numel() // c.shape[-1], c.shape[-1], act.shape[-1]
+        rows, H, I = act.shape[0], c.shape[-1], act.shape[-1]
         new = lambda *shape: torch.empty(*shape, device=c.device, dtype=torch.float32)
         d_out = d_out.contiguous()
-        p = _tail_problem(c, x, *params, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_t)
+        p = _tail_problem(c, x, *params, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_t, pick)
         sv = _lib.TailSaved()
         sv.h1, sv.st1, sv.a, sv.act, sv.h3, sv.st2 = (_ptr(t) for t in (h1, st1, a, act, h3, st2))
         io = _lib.TailBwdIO()
-        d_c = torch.empty_like(c) if need_c else None
-        d_x = torch.empty_like(x) if need_x else None
+        # with a row selection the kernel writes the picked positions only: the rest of the gradient is zero
+        alloc = torch.zeros_like if pick is not None else torch.empty_like
+        d_c = alloc(c) if need_c else None
+        d_x = alloc(x) if need_x else None
         io.d_out, io.d_ctx, io.d_x = _ptr(d_out), _ptr(d_c), _ptr(d_x)
         d_h1 = d_h2 = d_h3 = part = None
         if want_params:
@@ -95,11 +114,12 @@ class _FusedLayerTail(torch.autograd.Function):
         grads = [None] * 10  # wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2
         if want_params:
             two = lambda t: t.reshape(-1, t.shape[-1])
+            c_rows = two(c) if pick is None else c.gather(1, pick.unsqueeze(-1).expand(-1, -1, H)).view(-1, H)
             (gwd, gbd), (gw1, gb1), (gw2, gb2) = ops.linear_wgrad_grouped(
-                [(two(c), d_h1, True), (two(a), d_h2, True), (act, d_h3, True)])
+                [(c_rows, d_h1, True), (two(a), d_h2, True), (act, d_h3, True)])
             gb = ops.sum_rows(part, 0).view(4, H)  # (dgamma1, dbeta1, dgamma2, dbeta2)
             grads = [gwd, gbd, gb[0], gb[1], gw1, gb1, gw2, gb2, gb[2], gb[3]]
-        return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None, None)
+        return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None, None, None)
 
 
 
@@ -156,9 +176,15 @@ def supported(att, ffn) -> bool:
             and att.dense.bias is not None and ffn.dense_1.bias is not None and ffn.dense_2.bias is not None)
 
 
-def layer_tail(ctx_layer, input_tensor, att, ffn, keep_out=None, keep_ffn=None):
+def fused_supported(att, ffn) -> bool:
+    """The single-launch node covers this (hidden, inner) pair (it can also pick rows itself: layer_tail(pick=...))."""
+    return FUSED_KERNEL and bool(_lib.load().acattn_layer_tail_supported(att.dense.out_features, ffn.dense_1.out_features))
+
+
+def layer_tail(ctx_layer, input_tensor, att, ffn, keep_out=None, keep_ffn=None, pick=None):
     """FeedForward(attention_output(ctx_layer, input_tensor)) for one branch; `att` is the AttackRMultiHeadAttention
-    (dense, LayerNorm, out_dropout), `ffn` the FeedForward module.  keep_* feed explicit dropout masks (parity)."""
+    (dense, LayerNorm, out_dropout), `ffn` the FeedForward module.  keep_* feed explicit dropout masks (parity).
+    `pick` ([B, R] positions; fused node only): run on those positions of the two [B, L, H] inputs, return [B, R, H]."""
     training = att.training
     p1 = att.out_dropout.p if (training or keep_out is not None) else 0.0
     p2 = ffn.dropout.p if (training or keep_ffn is not None) else 0.0
@@ -166,10 +192,13 @@ def layer_tail(ctx_layer, input_tensor, att, ffn, keep_out=None, keep_ffn=None):
     seed1 = state.draw_seed() if (p1 > 0 and keep_out is None) else 0
     seed2 = state.draw_seed() if (p2 > 0 and keep_ffn is None) else 0
     seed_t = state.seed_tensor if (keep_out is None and keep_ffn is None) else None
+    extra = ()
     node = _LayerTail
-    if FUSED_KERNEL and _lib.load().acattn_layer_tail_supported(att.dense.out_features, ffn.dense_1.out_features):
-        node = _FusedLayerTail
+    if fused_supported(att, ffn):
+        node, extra = _FusedLayerTail, (pick,)
+    else:
+        assert pick is None, "row selection inside the tail needs the fused node"
     return node.apply(ctx_layer, input_tensor, att.dense.weight, att.dense.bias, att.LayerNorm.weight,
                             att.LayerNorm.bias, ffn.dense_1.weight, ffn.dense_1.bias, ffn.dense_2.weight,
                             ffn.dense_2.bias, ffn.LayerNorm.weight, ffn.LayerNorm.bias, att.LayerNorm.eps,
-                            ffn.LayerNorm.eps, p1, p2, keep_out, keep_ffn, seed1, seed2, seed_t, state)
+                            ffn.LayerNorm.eps, p1, p2, keep_out, keep_ffn, seed1, seed2, seed_t, state, *extra)

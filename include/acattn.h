@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 18
+#define ACATTN_ABI_VERSION 20
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -143,6 +143,11 @@ typedef struct acattn_ce_problem {
   const float* out;      /* [B,H] sequence representations (attacked_output / calibrated_output)  acsasrec.py:101-103 */
   const float* table;    /* [N,H] item_embedding.weight                                           acsasrec.py:117 */
   const int64_t* target; /* [B]   pos_items                                                      acsasrec.py:108 */
+  /* backward only: how `coef` (d loss / d row_loss) is read.  coef_is_scalar: coef[0] holds for every row (the
+   * cotangent of a mean, nn.CrossEntropyLoss's default reduction: acsasrec.py:119); coef_scale multiplies it
+   * (1 / B of that mean), 0 = 1. */
+  int32_t coef_is_scalar;
+  float coef_scale;
 } acattn_ce_problem;
 
 /* Bytes of scratch both CE entry points need (caller-allocated device memory, contents irrelevant). */
@@ -230,6 +235,20 @@ int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_
 int acattn_mask_penalty_fwd(const float* m, int64_t n, float* workspace, float* norm, void* stream);
 int acattn_mask_penalty_bwd(const float* m, const float* norm, const float* d_norm, int64_t n, float* d_m, void* stream);
 
+/* The attacked loss of the two-pass protocol assembled in one launch (acsasrec.py:129-137):
+ *     loss = -mean_b row_loss_b + weight * mean_l || 1 - M_l ||_2
+ * acattn_mask_penalty_partial: partial sums of (1 - m)^2 over one mask into `part` (ACATTN_PENALTY_WS_FLOATS floats).
+ * acattn_attacked_loss_finish: row_loss [B] from acattn_full_sort_ce_fwd[_dir]; part [n_masks, ACATTN_PENALTY_WS_FLOATS],
+ *   every mask of mask_numel elements; out [2 + n_masks] = (loss, mean row loss, norm_0, ...).  scale_buf (or NULL,
+ *   n_scale floats, at most a few 100k: one workgroup walks it) is multiplied by -1/B in place: pass the CE direction
+ *   so that d loss / d out = scale_buf * d_loss.
+ * acattn_mask_penalty_bwd_scaled: d_m = d_loss * scale * (m - 1) / norm, scale = weight / n_masks. */
+int acattn_mask_penalty_partial(const float* m, int64_t n, float* part, void* stream);
+int acattn_attacked_loss_finish(const float* row_loss, int32_t B, const float* part, int32_t n_masks, int64_t mask_numel,
+                                float weight, float* out, float* scale_buf, int32_t n_scale, void* stream);
+int acattn_mask_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n, float* d_m,
+                                   void* stream);
+
 /* Parameter gradients of y = x W^T + b (torch.nn.functional.linear as called for query/key/value, the attack
  * transforms, dense, the gate and the feed-forward pair: recbole/model/layers.py:687-690, 660-661, 681, 792-794, 863):
  *   dw[N,K] = sum_m dy[m,n] x[m,k]      db[N] = sum_m dy[m,n]  (db may be NULL)
@@ -276,6 +295,12 @@ typedef struct acattn_tail_problem {
   const uint8_t* keep2;
   uint64_t seed1, seed2;
   const uint64_t* seed_device;
+  /* Optional row selection: tail row r reads ctx / x at row (r / src_R) * src_L + src_index[r] (ctx, x are
+   * [*, src_L, H]; src_index [rows] positions, e.g. item_seq_len - 1 of abstract_recommender.py:130-134 with
+   * src_R = 1), and the backward ADDS the d_ctx / d_x rows there (a position may be picked twice): the caller
+   * zero-fills those two.  NULL = identity. */
+  const int64_t* src_index;
+  int32_t src_R, src_L;
 } acattn_tail_problem;
 
 /* Tensors the forward writes and the backward reads (all required in both directions, `act` forward only). */

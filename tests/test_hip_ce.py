@@ -65,3 +65,49 @@ def test_forward_with_direction_matches_materialised_logits(B, N, H, scale):
     assert (d_t.cpu() - g_tab.float()).abs().max() <= 1e-4 * g_tab.abs().max() + 1e-9
     mean = ce.full_sort_cross_entropy(o, t, target.to(DEV), table_grad=False)
     assert abs(mean.item() - ref_rows.mean().item()) <= 1e-5 * max(1.0, abs(ref_rows.mean().item()))
+
+
+def test_mean_node_scalar_cotangent_matches_rows_node():
+    """CrossEntropyLoss's default mean (acsasrec.py:119) as one node whose backward reads the cotangent as a device
+    scalar: same loss and gradients as mean(rows node)."""
+    B, N, H = 64, 3001, 64
+    g = torch.Generator().manual_seed(3)
+    out = (0.5 * torch.randn(B, H, generator=g)).to(DEV).requires_grad_(True)
+    table = (0.5 * torch.randn(N, H, generator=g)).to(DEV).requires_grad_(True)
+    target = torch.randint(0, N, (B,), generator=g).to(DEV)
+    a = ce.full_sort_cross_entropy(out, table, target)
+    b = ce.full_sort_cross_entropy_rows(out, table, target).mean()
+    assert abs(a.item() - b.item()) <= 1e-6 * abs(b.item())
+    ga = torch.autograd.grad(a * 1.7, [out, table])
+    gb = torch.autograd.grad(b * 1.7, [out, table])
+    for x, y in zip(ga, gb):
+        assert (x - y).abs().max() <= 1e-6 * y.abs().max() + 1e-9
+
+
+@pytest.mark.parametrize("B,N", [(64, 3001), (512, 100000)])
+def test_attacked_loss_node_matches_torch_expression(B, N):
+    """-CE + weight * mean_l ||1 - M_l|| (acsasrec.py:129-137) as one node against the same expression in fp64 torch
+    ops, loss and gradients (output, both masks; and the table when a caller asks for it)."""
+    from ac_tsr_amd.state import StepState
+    H, w = 64, 0.03
+    g = torch.Generator().manual_seed(B)
+    out = 0.5 * torch.randn(B, H, generator=g)
+    table = 0.5 * torch.randn(N, H, generator=g)
+    target = torch.randint(0, N, (B,), generator=g)
+    masks = [torch.rand(B, 2, 50, 50, generator=g) for _ in range(2)]
+    od, td = out.double().requires_grad_(True), table.double().requires_grad_(True)
+    md = [m.double().requires_grad_(True) for m in masks]
+    ref = -torch.nn.functional.cross_entropy(od @ td.t(), target) + w * torch.stack([torch.norm(1 - m, p=2) for m in md]).mean()
+    want = torch.autograd.grad(ref * 0.9, [od, td] + md)
+    o, t = out.to(DEV).requires_grad_(True), table.to(DEV).requires_grad_(True)
+    ms = [m.to(DEV).requires_grad_(True) for m in masks]
+    st = StepState()
+    loss = ce.attacked_loss(o, t, target.to(DEV), ms, w, st)
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    got = torch.autograd.grad(loss * 0.9, [o, t] + ms, retain_graph=True)
+    for x, y in zip(got, want):
+        assert (x.cpu() - y.float()).abs().max() <= 1e-4 * y.abs().max() + 1e-9
+    with st.attack_pass():  # the two-pass trainer: no table gradient, d output from the saved direction
+        got2 = torch.autograd.grad(loss * 0.9, [o] + ms)
+    for x, y in zip(got2, (want[0],) + tuple(want[2:])):
+        assert (x.cpu() - y.float()).abs().max() <= 1e-4 * y.abs().max() + 1e-9

@@ -266,9 +266,9 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(RuntimeError):  # gate built for seq_length 50 fed L = 40 (SURVEY 8c quirk i)
         enc = A.AttackRTransformerEncoder(combine_option="gate", seq_length=50).to(DEV).eval()
         enc(torch.zeros(2, 40, 64, device=DEV), torch.zeros(2, 1, 40, 40, device=DEV))
-    x128 = torch.zeros(2, 50, 128, device=DEV)
-    with pytest.raises(_lib.AcattnError):  # head size 128 is outside the supported set
-        A.calibrated_attention(x128, x128, x128, x128, x128, gl, m, A.AttentionConfig(n_heads=1), seed=1)
+    x256 = torch.zeros(2, 50, 256, device=DEV)
+    with pytest.raises(_lib.AcattnError):  # head size 256 is outside the supported set {16, 32, 64, 128}
+        A.calibrated_attention(x256, x256, x256, x256, x256, gl, m, A.AttentionConfig(n_heads=1), seed=1)
 
 
 @pytest.fixture

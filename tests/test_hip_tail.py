@@ -87,3 +87,26 @@ def test_fused_tail_counter_dropout_equals_unfused_node(rows):
     assert (other - outs[0]).abs().max() > 0.1
     again = _apply(tail._FusedLayerTail, dev, eps, p, None, None, 1234, 99, StepState())
     assert torch.equal(again, outs[0])
+
+
+def test_fused_tail_row_selection_equals_gather_then_tail():
+    """`pick`: the tail on selected positions of [B, L, H] inputs == gather, then the tail, then autograd's scatter
+    (the tail is position-wise, abstract_recommender.py:130-134 reads one position per sequence)."""
+    B, L, R, H, I, eps, p = 37, 50, 3, 64, 256, 1e-12, 0.5
+    t, g = _inputs(B * L, H, I, seed=11)
+    pick = torch.randint(0, L, (B, R), generator=g)
+    cot = torch.randn(B, R, H, generator=g).to(DEV)
+    dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
+    c3, x3 = dev["c"].view(B, L, H), dev["x"].view(B, L, H)
+    idx = pick.to(DEV)
+    args = [dev[k] for k in NAMES[2:]]
+    out_a = tail._FusedLayerTail.apply(c3, x3, *args, eps, eps, p, p, None, None, 5, 6, None, StepState(), idx)
+    index = idx.unsqueeze(-1).expand(-1, -1, H)
+    out_b = tail._FusedLayerTail.apply(c3.gather(1, index), x3.gather(1, index), *args, eps, eps, p, p, None, None, 5, 6,
+                                       None, StepState())
+    assert out_a.shape == (B, R, H) and torch.equal(out_a, out_b)
+    leaves = [dev[k] for k in NAMES]
+    ga = torch.autograd.grad((out_a * cot).sum(), leaves)
+    gb = torch.autograd.grad((out_b * cot).sum(), leaves)
+    for k, a, b in zip(NAMES, ga, gb):
+        assert (a - b).abs().max() <= 1e-6 * b.abs().max() + 1e-9, k
