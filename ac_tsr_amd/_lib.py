@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -53,7 +53,8 @@ class BwdIO(C.Structure):
         ("d_ctx_attacked", _f), ("d_ctx_calibrated", _f), ("d_attack_mask", _f),
         ("dq", _f), ("dk", _f), ("dv", _f), ("dqa", _f), ("dka", _f), ("dgate_logits", _f),
         ("dw_order_part", _f), ("dw_dist_part", _f), ("dsmall_part", _f), ("part_stride", C.c_int32),
-        ("active_qblocks", _f), ("attack_only", C.c_int32), ("workspace", _f),
+        ("active_qblocks", _f), ("attack_only", C.c_int32), ("workspace", _f), ("read_rows", _f),
+        ("n_read_rows", C.c_int32),
     ]
 
 
@@ -105,7 +106,7 @@ class TailBwdIO(C.Structure):
 class EmbedProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("n_table_rows", C.c_int64), ("idx", _f),
                 ("table", _f), ("pos", _f), ("gamma", _f), ("beta", _f), ("eps", C.c_float), ("p_drop", C.c_float),
-                ("keep", _f), ("seed", C.c_uint64), ("seed_device", _f)]
+                ("keep", _f), ("seed", C.c_uint64), ("seed_device", _f), ("nonzero_out", _f)]
 
 
 EMBED_BWD_CHUNKS = 8

@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   // A query block none of whose rows carries a cotangent contributes nothing anywhere: its wave only writes the zeros
   // the caller expects in dq, dqa and the gate partials (the last layer of the models is read at one position per
   // sequence, so three of its four blocks are such blocks in the calibrated-loss pass).
-  const bool block_active = !IO.active_qblocks || IO.d_attack_mask || ((IO.active_qblocks[b] >> qb) & 1u);
+  const bool block_active = qblock_active(IO, b, qb);
   if (block_active) {
     switch (nt) {
       case 1: body(std::integral_constant<int, 1>{}); break;

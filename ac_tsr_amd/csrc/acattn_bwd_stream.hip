@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(64, 2) acattn_bwd_row_kernel(const acattn_prob
   float* wrow = ws + (bh * L + (R.row_ok ? R.i : 0)) * NSC;
 
   // a query block none of whose rows carries a cotangent contributes nothing anywhere
-  const bool block_active = !IO.active_qblocks || IO.d_attack_mask || ((IO.active_qblocks[b] >> qb) & 1u);
+  const bool block_active = qblock_active(IO, b, qb);
   if (!block_active) {
     if (R.row_ok) {
       const f4 z = {0.f, 0.f, 0.f, 0.f};
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(64, 2) acattn_bwd_key_kernel(const acattn_prob
     const bool rows_see_a_key = causal ? F.first_valid <= i0 : F.any_valid;
     const int nt_q = rows_see_a_key ? min(causal ? min(nT, qb + 1) : nT, F.nt_valid) : nT;
     if (t >= nt_q) continue;  // the row kernel skipped this pair too: it carries no probability mass
-    if (IO.active_qblocks && !IO.d_attack_mask && !((IO.active_qblocks[b] >> qb) & 1u)) continue;
+    if (!qblock_active(IO, b, qb)) continue;
     Row<DH> R;
     load_row<DH>(P, IO, F, rowbase, bh, hoff, qb, c, g, R);
     const bool order_select = !causal || __ballot(R.dead) != 0ull;

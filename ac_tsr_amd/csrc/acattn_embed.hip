@@ -40,7 +40,10 @@ __global__ void __launch_bounds__(256) embed_ln_fwd_kernel(const acattn_embed_pr
     const float rstd = __builtin_amdgcn_rsqf(var + P.eps);
     const f4 keep = row_keep_scale(P.p_drop, P.keep, seed, row, c4, H);
     *(f4*)(y + (size_t)row * H + 4 * c4) = ((d * rstd) * gm + bt) * keep;
-    if (c4 == 0) *(float2*)(stats + 2 * (size_t)row) = float2{mean, rstd};
+    if (c4 == 0) {
+      *(float2*)(stats + 2 * (size_t)row) = float2{mean, rstd};
+      if (P.nonzero_out) P.nonzero_out[row] = P.idx[row] != 0;
+    }
   }
 }
 

@@ -24,8 +24,9 @@
 // as dwords straight from the row-major parameters (no transposed copies).  The weight/bias gradients stay with
 // acattn_linear_wgrad_grouped, which reads the d_h1 / d_h2 / d_h3 tiles this kernel writes when asked to.
 //
-// Measured (MI355X, rocprofv3, 25,600 rows / 512 rows; profiles/r02_tail_kernels.txt): forward 38.6 / 17.5 us,
-// backward 50.9 / 24.9 us, against 6 + ~15 launches of 275 / 117 us in total per forward + two backward walks.
+// Measured (MI355X, rocprofv3, 25,600 rows / 512 rows; profiles/r02_tail_kernels.txt): forward 38.3 / 14.0 us,
+// backward 51.0 / 14.6 us (512 rows: four waves per row block, 17.8 / 24.5 with one), against 6 + ~15 launches of
+// 266 / 107 us in total per forward + two backward walks.  The four-wave split on 25,600 rows: 67 / 65 us.
 // What bounds it: the fp32 MFMAs (576 forward, 784 backward per 16 rows, 32 cycles each) share the issue port with
 // the VALU work between them (GELU, LayerNorm, address arithmetic: about +40 %), and 1,600 row blocks on 1,024 SIMDs
 // leave the critical SIMD with two blocks.  Without the stores 37.5 us, without GELU 34.0, without both 33.7, with the
@@ -33,6 +34,8 @@
 //
 // Dropout decisions: row_keep_scale() of acattn_rowops.h, i.e. exactly those of acattn_ln.hip for the same
 // (seed, row, column): the fused and the unfused formulation are interchangeable between forward and backward.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "acattn_common.h"
@@ -43,7 +46,12 @@ int acattn_tail_bwd_partial_rows(int rows);
 namespace {
 
 int g_tail_nb = 0;  // rows per wave / 16; 0 = by size (measurement hook: acattn_select_layer_tail_blocks)
-int rows_per_wave(int rows) { return 16 * (g_tail_nb ? g_tail_nb : (rows >= 16384 ? 2 : 1)); }
+// four waves per row block while one wave per block would leave most SIMDs without work
+bool split_slabs(int rows) {
+  static const int limit = getenv("ACATTN_TAIL_SPLIT_ROWS") ? atoi(getenv("ACATTN_TAIL_SPLIT_ROWS")) : 4096;
+  return g_tail_nb == 0 && rows <= limit;
+}
+int rows_per_wave(int rows) { return split_slabs(rows) ? 16 : 16 * (g_tail_nb ? g_tail_nb : (rows >= 16384 ? 2 : 1)); }
 
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
@@ -123,10 +131,16 @@ __device__ __forceinline__ void ln_forward(const f4 (&z)[DT], const f4 (&res)[DT
 // -----------------------------------------------------------------------------------------------------------------
 // forward
 // -----------------------------------------------------------------------------------------------------------------
-template <int H, int I, int NB>
-__global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
+// NW = waves that share one 16-row block (1 or 4).  With few rows (the 512 read positions of the last layer: 32
+// blocks) one wave per block leaves the chip empty and the launch lasts as long as one wave's whole chain; with
+// NW = 4 every wave forms `a` for itself (64 MFMAs, cheap) and then takes every fourth slab of the inner dimension;
+// the four partial products meet in LDS and wave 0 finishes.
+template <int H, int I, int NB, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) tail_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
+  static_assert(NW == 1 || NB == 1, "the slab split works on one row block");
   constexpr int DT = H / 16, IT = I / 16;
-  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+  const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const Rows<NB> W = wave_rows<NB>(P);
   const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
 
@@ -171,7 +185,7 @@ __global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem 
     }
     float mean, rstd;
     ln_forward<DT>(h1[nb], res, keep, P.g1, P.b1, P.eps1, g, a[nb], mean, rstd);
-    if (W.ok[nb]) {
+    if (W.ok[nb] && wave == 0) {
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem 
   f4 h3[NB][DT];
 #pragma unroll
   for (int nt = 0; nt < DT; ++nt) {
-    const f4 b = *(const f4*)(P.bb2 + 16 * nt + 4 * g);
+    const f4 b = wave == 0 ? *(const f4*)(P.bb2 + 16 * nt + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) h3[nb][nt] = b;
   }
@@ -206,10 +220,10 @@ __global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem 
     s.b1 = *(const f4*)(P.bb1 + 16 * mt + 4 * g);
   };
   Slab cur, nxt;
-  load_slab(0, cur);
+  load_slab(wave, cur);
 #pragma unroll 2
-  for (int mt = 0; mt < IT; ++mt) {
-    load_slab(mt + 1 < IT ? mt + 1 : mt, nxt);
+  for (int mt = wave; mt < IT; mt += NW) {
+    load_slab(mt + NW < IT ? mt + NW : mt, nxt);
     f4 h2[NB][2];  // two partial accumulators: a dependent 16x16x4 chain issues every 40 cycles, alternating every 32
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) h2[nb][0] = h2[nb][1] = f4{0.f, 0.f, 0.f, 0.f};
@@ -232,6 +246,20 @@ __global__ void __launch_bounds__(64) tail_fwd_kernel(const acattn_tail_problem 
         for (int nt = 0; nt < DT; ++nt) h3[nb][nt] = mfma16(cur.w2[nt][r], act[r], h3[nb][nt]);
     }
     cur = nxt;
+  }
+
+  if (NW > 1) {  // fold the waves' partial products into wave 0
+    __shared__ f4 red[NW > 1 ? NW - 1 : 1][DT][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) red[wave - 1][t][threadIdx.x & 63] = h3[0][t];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) h3[0][t] += red[w][t][threadIdx.x & 63];
   }
 
   // ---- out = LayerNorm(dropout(h3) + a) -------------------------------------------------------------------------
@@ -305,11 +333,13 @@ __device__ __forceinline__ void store_grad(float* dst, f4 v, bool accumulate) {
   }
 }
 
-template <int H, int I, int NB>
-__global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
-                                                      const acattn_tail_bwd_io IO) {
+template <int H, int I, int NB, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) tail_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
+                                                           const acattn_tail_bwd_io IO) {
+  static_assert(NW == 1 || NB == 1, "the slab split works on one row block");
   constexpr int DT = H / 16, IT = I / 16;
-  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+  const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;  // see the forward
   const Rows<NB> W = wave_rows<NB>(P);
   const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
   float* part = IO.dgb_part ? IO.dgb_part + (size_t)blockIdx.x * 4 * H : nullptr;
@@ -336,10 +366,11 @@ __global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem 
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         dh3[nb][t] = da[nb][t] * keep[t];
-        if (IO.d_h3 && W.ok[nb]) *(f4*)(IO.d_h3 + (size_t)W.row[nb] * H + 16 * t + 4 * g) = dh3[nb][t];
+        if (IO.d_h3 && W.ok[nb] && wave == 0) *(f4*)(IO.d_h3 + (size_t)W.row[nb] * H + 16 * t + 4 * g) = dh3[nb][t];
+        if (wave > 0) da[nb][t] = f4{0.f, 0.f, 0.f, 0.f};  // the residual share of d a travels with wave 0
       }
     }
-    if (part) {
+    if (part && wave == 0) {
       store_partial<DT>(part + 2 * H, acc_g, c, g);
       store_partial<DT>(part + 3 * H, acc_b, c, g);
     }
@@ -365,10 +396,10 @@ __global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem 
     s.b1 = *(const f4*)(P.bb1 + 16 * mt + 4 * g);
   };
   Slab cur, nxt;
-  load_slab(0, cur);
+  load_slab(wave, cur);
 #pragma unroll 2
-  for (int mt = 0; mt < IT; ++mt) {
-    load_slab(mt + 1 < IT ? mt + 1 : mt, nxt);  // one slab ahead (see the forward)
+  for (int mt = wave; mt < IT; mt += NW) {
+    load_slab(mt + NW < IT ? mt + NW : mt, nxt);  // one slab ahead (see the forward)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       f4 h2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, dact[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
@@ -390,6 +421,20 @@ __global__ void __launch_bounds__(64) tail_bwd_kernel(const acattn_tail_problem 
         for (int nt = 0; nt < DT; ++nt) da[nb][nt] = mfma16(cur.w1t[nt][r], dh2[r], da[nb][nt]);
     }
     cur = nxt;
+  }
+
+  if (NW > 1) {  // fold the waves' shares of d a into wave 0
+    __shared__ f4 red[NW > 1 ? NW - 1 : 1][DT][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) red[wave - 1][t][threadIdx.x & 63] = da[0][t];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) da[0][t] += red[w][t][threadIdx.x & 63];
   }
 
   // ---- through the first LayerNorm: d h1, d x; then d ctx = d h1 . Wd ---------------------------------------------
@@ -459,6 +504,10 @@ template <int H, int I>
 int launch_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
   const int nb = rows_per_wave(p.rows) / 16;
   const int blocks = (p.rows + 16 * nb - 1) / (16 * nb);
+  if (nb == 1 && split_slabs(p.rows)) {
+    hipLaunchKernelGGL((tail_fwd_kernel<H, I, 1, 4>), dim3(blocks), dim3(256), 0, stream, p, s);
+    return (int)hipGetLastError();
+  }
   if (nb == 2)
     hipLaunchKernelGGL((tail_fwd_kernel<H, I, 2>), dim3(blocks), dim3(64), 0, stream, p, s);
   else
@@ -470,6 +519,10 @@ template <int H, int I>
 int launch_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const acattn_tail_bwd_io& io, hipStream_t stream) {
   const int nb = rows_per_wave(p.rows) / 16;
   const int blocks = acattn_tail_bwd_partial_rows(p.rows);
+  if (nb == 1 && split_slabs(p.rows)) {
+    hipLaunchKernelGGL((tail_bwd_kernel<H, I, 1, 4>), dim3(blocks), dim3(256), 0, stream, p, s, io);
+    return (int)hipGetLastError();
+  }
   if (nb == 2)
     hipLaunchKernelGGL((tail_bwd_kernel<H, I, 2>), dim3(blocks), dim3(64), 0, stream, p, s, io);
   else

@@ -49,15 +49,18 @@ class _EmbedLayerNorm(torch.autograd.Function):
         p = _problem(idx, table, pos, gamma, beta, eps, p_drop, keep, seed, seed_tensor)
         y = torch.empty(*idx.shape, table.shape[1], device=table.device, dtype=torch.float32)
         stats = torch.empty(p.rows, 2, device=table.device, dtype=torch.float32)
+        nonzero = torch.empty(idx.shape, device=table.device, dtype=torch.uint8)  # idx != 0: the mask's validity bytes
+        p.nonzero_out = _ptr(nonzero)
         _lib.check(lib.acattn_embed_layernorm_fwd(C.byref(p), _ptr(y), _ptr(stats), _stream()), "embed_layernorm_fwd")
         empty = torch.empty(0)
         ctx.save_for_backward(idx, table, pos if pos is not None else empty, gamma, beta, stats,
                               keep if keep is not None else empty, seed_tensor if seed_tensor is not None else empty)
         ctx.args = (eps, p_drop, pos is not None, keep is not None, seed, seed_tensor is not None, padding_idx)
-        return y
+        ctx.mark_non_differentiable(nonzero)
+        return y, nonzero
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _d_nonzero=None):
         idx, table, pos, gamma, beta, stats, keep, seed_tensor = ctx.saved_tensors
         eps, p_drop, has_pos, has_keep, seed, has_seed_t, padding_idx = ctx.args
         if ctx.state.attack_pass_only:  # none of these parameters is an attack transform (trainer.py:678-684)
@@ -87,15 +90,18 @@ class _EmbedLayerNorm(torch.autograd.Function):
 
 def embed_layer_norm(item_seq: torch.Tensor, item_embedding: torch.nn.Embedding,
                      position_embedding: Optional[torch.nn.Embedding], norm: torch.nn.LayerNorm, p_drop: float,
-                     training: bool, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dropout(norm(item_embedding(item_seq) + position_embedding(arange(L))), p_drop, training) -> [B, L, H]."""
+                     training: bool, keep: Optional[torch.Tensor] = None, return_nonzero: bool = False):
+    """dropout(norm(item_embedding(item_seq) + position_embedding(arange(L))), p_drop, training) -> [B, L, H];
+    with `return_nonzero` also `item_seq != 0` as bytes [B, L] (written by the same launch: the structured mask's
+    key validity, abstract_recommender.py:137)."""
     p = p_drop if (training or keep is not None) else 0.0
     state = state_of(norm)
     seed = state.draw_seed() if (p > 0 and keep is None) else 0
-    return _EmbedLayerNorm.apply(item_seq.contiguous(), item_embedding.weight,
-                                 None if position_embedding is None else position_embedding.weight, norm.weight,
-                                 norm.bias, norm.eps, p, keep, seed, state.seed_tensor if keep is None else None,
-                                 item_embedding.padding_idx, state)
+    y, nonzero = _EmbedLayerNorm.apply(item_seq.contiguous(), item_embedding.weight,
+                                       None if position_embedding is None else position_embedding.weight, norm.weight,
+                                       norm.bias, norm.eps, p, keep, seed, state.seed_tensor if keep is None else None,
+                                       item_embedding.padding_idx, state)
+    return (y, nonzero) if return_nonzero else y
 
 
 def supported(hidden_size: int) -> bool:

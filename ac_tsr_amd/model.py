@@ -43,24 +43,26 @@ def _penalty(attack_mask):
     return torch.norm(1 - attack_mask, p=2)
 
 
-def _front_end(model, item_seq, keep_emb=None):
-    """dropout(LayerNorm(item_embedding(item_seq) + position_embedding)): acsasrec.py:87-95 == acbert4rec.py:163-171.
-    One fused launch each way on the HIP path (fused_embed); hidden sizes it does not cover take the same chain as
-    separate device ops."""
+def _front_end(model, item_seq, keep_emb=None, bidirectional=False):
+    """(dropout(LayerNorm(item_embedding(item_seq) + position_embedding)), structured mask): acsasrec.py:87-98 ==
+    acbert4rec.py:163-173.  One fused launch each way on the HIP path (fused_embed), which also writes the mask's
+    key-validity bytes (item_seq != 0); hidden sizes it does not cover take the same chain as separate device ops."""
     pos = model.position_embedding if model.use_position_embedding else None
     if pos is not None and item_seq.size(1) > pos.num_embeddings:
         raise IndexError("index out of range in self")  # what nn.Embedding raises on the host
     if item_seq.is_cuda and fused_embed.supported(model.hidden_size):
-        return fused_embed.embed_layer_norm(item_seq, model.item_embedding, pos, model.LayerNorm, model.dropout.p,
-                                            model.training, keep_emb)
+        emb, nonzero = fused_embed.embed_layer_norm(item_seq, model.item_embedding, pos, model.LayerNorm, model.dropout.p,
+                                                    model.training, keep_emb, return_nonzero=True)
+        return emb, StructuredMask(key_valid=nonzero, causal=not bidirectional)
     input_emb = embedding_lookup(item_seq, model.item_embedding)
     if pos is not None:
         position_ids = torch.arange(item_seq.size(1), dtype=torch.long, device=item_seq.device)
         input_emb = input_emb + pos(position_ids).unsqueeze(0)
     input_emb = model.LayerNorm(input_emb)
+    mask = model.get_structured_mask(item_seq, bidirectional)
     if keep_emb is not None:
-        return input_emb * (keep_emb.to(input_emb.dtype) / (1.0 - model.dropout.p))
-    return model.dropout(input_emb)
+        return input_emb * (keep_emb.to(input_emb.dtype) / (1.0 - model.dropout.p)), mask
+    return model.dropout(input_emb), mask
 
 
 class SequentialRecommender(nn.Module):
@@ -162,8 +164,7 @@ class ACSASRec(SequentialRecommender):
             module.bias.data.zero_()
 
     def forward(self, item_seq, item_seq_len, is_train=False, _rnds=None, _keep_emb=None):
-        input_emb = _front_end(self, item_seq, _keep_emb)
-        mask = self.get_structured_mask(item_seq, self.bidirectional)
+        input_emb, mask = _front_end(self, item_seq, _keep_emb, self.bidirectional)
         # only position item_seq_len - 1 of the last layer is read (acsasrec.py:100-103): the encoder is told, so the
         # last layer's position-wise tail runs on B rows instead of B * L (gather and tail commute)
         if not self.step_state.prune_dead_work:  # the reference's full schedule (acsasrec.py:99-103)
@@ -364,8 +365,7 @@ class AcBERT4Rec(SequentialRecommender):
     def forward(self, item_seq, _rnds=None, _keep_emb=None, _rows=None):
         """(attacked [B,L,H], calibrated [B,L,H], attack masks); with `_rows` ([B,R] positions) only those positions
         of the two outputs, [B,R,H] (see AttackRTransformerLayer.forward)."""
-        input_emb = _front_end(self, item_seq, _keep_emb)
-        mask = self.get_structured_mask(item_seq, bidirectional=True)
+        input_emb, mask = _front_end(self, item_seq, _keep_emb, bidirectional=True)
         if not self.step_state.prune_dead_work:  # the reference's full schedule, rows picked afterwards (acbert4rec.py:219-225)
             trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=True, _rnds=_rnds)
             attacked_output, calibrated_output = trm_output[0][-1]

@@ -177,10 +177,11 @@ class _CalibratedAttention(torch.autograd.Function):
         ctx.state = state
         ctx.set_materialize_grads(False)  # an output nobody differentiated arrives as None, not as a zero tensor
         ctx.active_qblocks = None
+        ctx.read_rows = None
         if read_rows is not None:
             # bit q of entry b: some read position of sequence b lies in query block q (16 rows per block)
-            if read_rows.shape[1] == 1:
-                ctx.active_qblocks = torch.bitwise_left_shift(1, read_rows.view(-1) >> 4).to(torch.int32)
+            if read_rows.shape[1] <= 4:
+                ctx.read_rows = read_rows.contiguous()  # the kernels derive the block bits from the positions themselves
             else:
                 blocks = torch.zeros(B, (L + 15) // 16, dtype=torch.int32, device=q.device).scatter_(
                     1, (read_rows >> 4), 1)
@@ -253,6 +254,8 @@ class _CalibratedAttention(torch.autograd.Function):
         io.part_stride = width
         # the hint is only valid when the mask cotangent (which reaches every row) is absent
         io.active_qblocks = _ptr(ctx.active_qblocks) if (ctx.active_qblocks is not None and d_M is None) else None
+        if ctx.read_rows is not None and d_M is None:
+            io.read_rows, io.n_read_rows = _ptr(ctx.read_rows), ctx.read_rows.shape[1]
         # pass 2 through a layer with nothing attack-related upstream: only the attack transforms' inputs matter
         attack_only = ctx.state.attack_pass_only and not ctx.attack_upstream
         io.attack_only = int(attack_only)

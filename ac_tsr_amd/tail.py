@@ -101,9 +101,12 @@ class _FusedLayerTail(torch.autograd.Function):
         sv.h1, sv.st1, sv.a, sv.act, sv.h3, sv.st2 = (_ptr(t) for t in (h1, st1, a, act, h3, st2))
         io = _lib.TailBwdIO()
         # with a row selection the kernel writes the picked positions only: the rest of the gradient is zero
-        alloc = torch.zeros_like if pick is not None else torch.empty_like
-        d_c = alloc(c) if need_c else None
-        d_x = alloc(x) if need_x else None
+        if pick is not None and need_c and need_x:
+            d_c, d_x = torch.zeros(2, *c.shape, device=c.device, dtype=c.dtype).unbind(0)  # one fill launch for both
+        else:
+            alloc = torch.zeros_like if pick is not None else torch.empty_like
+            d_c = alloc(c) if need_c else None
+            d_x = alloc(x) if need_x else None
         io.d_out, io.d_ctx, io.d_x = _ptr(d_out), _ptr(d_c), _ptr(d_x)
         d_h1 = d_h2 = d_h3 = part = None
         if want_params:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 20
+#define ACATTN_ABI_VERSION 21
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -134,6 +134,10 @@ typedef struct acattn_bwd_io {
   void* workspace;      /* optional device scratch of acattn_calibrated_attention_bwd_workspace_bytes(p) bytes (contents
                            irrelevant).  With it, long sequences (L > 64) take the streaming two-kernel backward
                            (acattn_bwd_stream.hip); NULL = the row-resident kernels only. */
+  const int64_t* read_rows; /* the same hint as active_qblocks in its raw form: [B, n_read_rows] positions whose context
+                           cotangents are the only non-zero ones (item_seq_len - 1 of abstract_recommender.py:130-134).
+                           Consulted when active_qblocks is NULL; NULL = all active. */
+  int32_t n_read_rows;
 } acattn_bwd_io;
 
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
@@ -211,6 +215,8 @@ typedef struct acattn_embed_problem {
   const uint8_t* keep;    /* optional explicit keep mask [rows,H]; NULL = counter RNG from (seed, seed_device) */
   uint64_t seed;
   const uint64_t* seed_device;
+  uint8_t* nonzero_out;   /* optional [rows]: receives idx != 0, the key-validity bytes of the structured mask
+                             (abstract_recommender.py:137: attention_mask = item_seq != 0); forward only */
 } acattn_embed_problem;
 
 /* stats[rows,2] receives (mean, 1/std) per row for the backward. */

@@ -45,9 +45,11 @@ def test_embed_layernorm_matches_torch(B, L, H, N, with_pos, p):
     # fused
     emb_c, norm_c = emb.to(DEV), norm.to(DEV)
     pos_c = pos.to(DEV) if with_pos else None
-    y = fused_embed.embed_layer_norm(idx.to(DEV), emb_c, pos_c, norm_c, p, training=False,
-                                     keep=None if keep is None else keep.to(DEV))
+    y, nonzero = fused_embed.embed_layer_norm(idx.to(DEV), emb_c, pos_c, norm_c, p, training=False,
+                                              keep=None if keep is None else keep.to(DEV), return_nonzero=True)
     assert (y.detach().cpu() - ref.detach().float()).abs().max() <= 3e-5
+    # the same launch writes the structured mask's key-validity bytes (abstract_recommender.py:137)
+    assert nonzero.dtype == torch.uint8 and torch.equal(nonzero.cpu(), (idx != 0).to(torch.uint8))
     got = torch.autograd.grad((y * cot.to(DEV)).sum(), [emb_c.weight, norm_c.weight, norm_c.bias] +
                               ([pos_c.weight] if with_pos else []))
     for a, b in zip(got, grads):

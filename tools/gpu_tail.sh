@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r2/tailp
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for cfg in "25600 1" "25600 2" "512 1" "25600 0 unfused" "512 0 unfused"; do
+for cfg in "25600 1" "25600 2" "512 1" "512 0" "4096 0" "25600 0 unfused" "512 0 unfused"; do
   tag=$(echo $cfg | tr ' ' '_')
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag -o t -- python3 $R/tools/tail_bench.py $cfg > $O/$tag.log 2>&1 || exit 1
   echo "== $cfg"
