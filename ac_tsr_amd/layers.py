@@ -192,16 +192,16 @@ class AttackRTransformerLayer(nn.Module):
         if _rows is not None:
             index = _rows.unsqueeze(-1).expand(-1, -1, hidden_states.shape[-1])
             pick = lambda t: None if t is None else t.gather(1, index)
-            picks_itself = (ctx_att.is_cuda and torch.is_grad_enabled() and tail.supported(att, self.feed_forward)
-                            and tail.fused_supported(att, self.feed_forward))
+            picks_itself = ctx_cal.is_cuda and tail.supported(att, self.feed_forward) and tail.fused_supported(att, self.feed_forward)
             if not picks_itself:
                 residual = pick(hidden_states)
         else:
             pick = lambda t: t
 
         def branch(ctx_layer, keep_out, keep_ffn):
-            fused = ctx_layer.is_cuda and torch.is_grad_enabled() and tail.supported(att, self.feed_forward)
-            if fused and _rows is not None and tail.fused_supported(att, self.feed_forward):
+            one_launch = ctx_layer.is_cuda and tail.supported(att, self.feed_forward) and tail.fused_supported(att, self.feed_forward)
+            fused = one_launch or (ctx_layer.is_cuda and torch.is_grad_enabled() and tail.supported(att, self.feed_forward))
+            if one_launch and _rows is not None:
                 # the fused tail picks the rows itself: no gather launches in front of it, no scatter launches behind
                 return tail.layer_tail(ctx_layer, hidden_states, att, self.feed_forward, pick(keep_out), pick(keep_ffn),
                                        pick=_rows)

@@ -230,15 +230,15 @@ class _FusedProjections(torch.autograd.Function):
 def projections(x, query, key, value, attack_query, attack_key, gate=None, attack_upstream=True):
     """(mq, mk, mv, qa, ka, gate_logits or None) of one encoder layer; see _Projections.  `attack_upstream=False`
     tells the node that nothing that produced `x` holds attack transforms (the first encoder layer)."""
-    if not x.is_cuda or not torch.is_grad_enabled():
-        mq, mk, mv = query(x), key(x), value(x)
-        return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None)
-    node = _Projections
-    if FUSED_PROJECTIONS and x.dtype == torch.float32 and all(
+    node = _Projections if torch.is_grad_enabled() else None
+    if x.is_cuda and FUSED_PROJECTIONS and x.dtype == torch.float32 and all(
             m.bias is not None for m in (query, key, value, attack_query, attack_key) + ((gate,) if gate is not None else ())):
         from . import _lib
         if _lib.load().acattn_projections_supported(x.shape[-1], gate.out_features if gate is not None else 0):
-            node = _FusedProjections
+            node = _FusedProjections  # the single launch serves evaluation (no_grad) as well
+    if not x.is_cuda or node is None:
+        mq, mk, mv = query(x), key(x), value(x)
+        return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None)
     return node.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
                               attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
                               gate.weight if gate is not None else None, gate.bias if gate is not None else None,

@@ -111,3 +111,26 @@ def test_attacked_loss_node_matches_torch_expression(B, N):
         got2 = torch.autograd.grad(loss * 0.9, [o] + ms)
     for x, y in zip(got2, (want[0],) + tuple(want[2:])):
         assert (x.cpu() - y.float()).abs().max() <= 1e-4 * y.abs().max() + 1e-9
+
+
+def test_attacked_loss_node_without_the_direction_sweep():
+    """Rows x catalogue beyond the per-workgroup slab budget of the direction sweep (acattn_full_sort_ce_fwd_dir returns
+    -100): the node falls back to the plain forward and the regular backward sweep with a scalar cotangent."""
+    from ac_tsr_amd.state import StepState
+    B, N, H, w = 9000, 20000, 64, 0.03
+    g = torch.Generator().manual_seed(1)
+    out = 0.3 * torch.randn(B, H, generator=g)
+    table = 0.3 * torch.randn(N, H, generator=g)
+    target = torch.randint(0, N, (B,), generator=g)
+    mask = torch.rand(4, 2, 50, 50, generator=g)
+    od, md = out.double().requires_grad_(True), mask.double().requires_grad_(True)
+    ref = -torch.nn.functional.cross_entropy(od @ table.double().t(), target) + w * torch.norm(1 - md, p=2)
+    want = torch.autograd.grad(ref, [od, md])
+    o, m = out.to(DEV).requires_grad_(True), mask.to(DEV).requires_grad_(True)
+    st = StepState()
+    loss = ce.attacked_loss(o, table.to(DEV), target.to(DEV), [m], w, st)
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    with st.attack_pass():
+        got = torch.autograd.grad(loss, [o, m])
+    for x, y in zip(got, want):
+        assert (x.cpu() - y.float()).abs().max() <= 1e-4 * y.abs().max() + 1e-9
