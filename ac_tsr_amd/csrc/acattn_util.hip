@@ -210,6 +210,9 @@ int acattn_launch_sum_rows(const float* x, float* out, int batch, int R, int C, 
   const int c4 = (C + 3) / 4;
   int CT = 256;
   while (CT > 1 && CT / 2 >= c4) CT /= 2;  // smallest power of two >= c4, capped at 256
+  // few, narrow outputs over many rows (1,024 x 132 calibrator partials: one workgroup, 20 us): give a workgroup
+  // fewer columns and more row lanes until about 32 workgroups share the reduction
+  while (CT > 1 && (int64_t)batch * ((c4 + CT - 1) / CT) < 32 && R >= 4 * (256 / CT)) CT /= 2;
   const int col_groups = (c4 + CT - 1) / CT;
   // one chunk: every output element is written by exactly one workgroup (no atomics, no zero-fill).  Callers that
   // need more parallelism over a long R split it themselves into [batch * s, R / s, C] and reduce twice (ops.sum_rows)

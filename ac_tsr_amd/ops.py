@@ -347,9 +347,8 @@ def sum_rows(x: torch.Tensor, dim: int = 0) -> torch.Tensor:
     out_shape = tuple(x.shape[:dim]) + tuple(x.shape[dim + 1:])
     Cn = x.numel() // (batch * R)
     wgs = batch * ((Cn + 1023) // 1024)
-    # a single workgroup per batch is latency-bound (1,024 x 132: 20 us in one stage, 10 in two; the layer tail's
-    # LayerNorm partials, 800 x 256, likewise)
-    if wgs < 128 and (R >= 1024 or (R >= 64 and R * min(Cn, 1024) * 4 >= (768 << 10))):
+    # (medium reductions with few columns are spread over ~32 workgroups by the launcher itself)
+    if wgs < 128 and R >= 4096:
         s = 1
         for cand in range(2, 257):
             if R % cand == 0 and R // cand >= 8:
