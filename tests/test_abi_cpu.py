@@ -44,7 +44,10 @@ def test_ctypes_layout_matches_c(tmp_path):
     """Compile a tiny C program against include/acattn.h and compare sizeof/offsetof with ctypes."""
     fields = {"acattn_problem": _lib.Problem, "acattn_fwd_out": _lib.FwdOut, "acattn_bwd_io": _lib.BwdIO,
               "acattn_ce_problem": _lib.CeProblem, "acattn_ln_problem": _lib.LnProblem,
-              "acattn_embed_problem": _lib.EmbedProblem}
+              "acattn_embed_problem": _lib.EmbedProblem, "acattn_proj_problem": _lib.ProjProblem,
+              "acattn_proj_out": _lib.ProjOut, "acattn_proj_bwd_io": _lib.ProjBwdIO,
+              "acattn_tail_problem": _lib.TailProblem, "acattn_tail_saved": _lib.TailSaved,
+              "acattn_tail_bwd_io": _lib.TailBwdIO}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "acattn.h"', 'int main(void){']
     for cname, cls in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -85,6 +88,15 @@ def test_validation_errors_without_gpu(lib):
     p.L = 500
     assert lib.acattn_calibrated_attention_fwd(C.byref(p), C.byref(o), None) < 0
     assert b"sequence length" in lib.acattn_last_error()
+    # the layer-level launches validate before touching the device as well
+    tp, ts = _lib.TailProblem(), _lib.TailSaved()
+    tp.rows, tp.H, tp.I = 16, 96, 256
+    assert lib.acattn_layer_tail_fwd(C.byref(tp), C.byref(ts), None) < 0 and b"hidden_size" in lib.acattn_last_error()
+    assert lib.acattn_layer_tail_supported(64, 256) == 1 and lib.acattn_layer_tail_supported(128, 256) == 0
+    pp, po = _lib.ProjProblem(), _lib.ProjOut()
+    pp.rows, pp.H, pp.G = 16, 64, 80
+    assert lib.acattn_projections_fwd(C.byref(pp), C.byref(po), None) < 0 and b"gate" in lib.acattn_last_error()
+    assert lib.acattn_projections_supported(64, 50) == 1 and lib.acattn_projections_supported(128, 50) == 0
 
 
 def test_cpu_tensors_fail_loudly(lib):
