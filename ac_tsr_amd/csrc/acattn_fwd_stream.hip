@@ -169,8 +169,16 @@ __global__ void __launch_bounds__(64, (stream_waves<DH, NT>())) acattn_fwd_strea
   };
   // row fragment of X in {K, Ka} for key tile t: the A operand of S^T = X.Q^T (rows past L repeat the last row: their
   // keys are masked)
-  auto key_frag = [&](const float* X, int t, f4 (&out)[KS / 4]) {
-    const float* p = X + (rowbase + min(16 * t + c, L - 1)) * H + hoff + KS * g;
+  // (row offsets are formed as min(lane part + tile part, last row) in elements: an add and a min per row instead of
+  // a 32-bit multiply, which issues at a quarter of the rate -- 15-19 of them per key tile and pass before)
+  const int last_row = (L - 1) * H;
+  const int key_lane = c * H + hoff + KS * g;      // row c of a tile, this lane's slice of the head
+  const int val_lane = 4 * g * H + hoff + c;       // row 4 g of a tile, column c of the head
+  const float* const kbase = P.k + rowbase * H;
+  const float* const kabase = P.ka + rowbase * H;
+  const float* const vbase = P.v + rowbase * H;
+  auto key_frag = [&](const float* Xb, int t, f4 (&out)[KS / 4]) {
+    const float* p = Xb + min(key_lane + 16 * t * H, last_row + hoff + KS * g);
 #pragma unroll
     for (int s4 = 0; s4 < KS / 4; ++s4) out[s4] = *(const f4*)(p + 4 * s4);
   };
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(64, (stream_waves<DH, NT>())) acattn_fwd_strea
   auto value_frag = [&](int t, float (&vf)[4][DT]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float* p = P.v + (rowbase + min(16 * t + 4 * g + r, L - 1)) * H + hoff + c;
+      const float* p = vbase + min(val_lane + (16 * t + r) * H, last_row + hoff + c);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) vf[r][dt] = p[16 * dt];
     }
@@ -190,8 +198,8 @@ __global__ void __launch_bounds__(64, (stream_waves<DH, NT>())) acattn_fwd_strea
   // the fragments of tile t + 1 are requested before tile t is worked on: a wave's chain of L2 round trips would
   // otherwise be as long as its arithmetic
   f4 kq[KS / 4], kaq[KS / 4];
-  key_frag(P.k, 0, kq);
-  if (ADV) key_frag(P.ka, 0, kaq);
+  key_frag(kbase, 0, kq);
+  if (ADV) key_frag(kabase, 0, kaq);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (t < nt) {
@@ -202,8 +210,8 @@ __global__ void __launch_bounds__(64, (stream_waves<DH, NT>())) acattn_fwd_strea
         if (ADV) ka4[s4] = kaq[s4];
       }
       if (t + 1 < NT && t + 1 < nt) {
-        key_frag(P.k, t + 1, kq);
-        if (ADV) key_frag(P.ka, t + 1, kaq);
+        key_frag(kbase, t + 1, kq);
+        if (ADV) key_frag(kabase, t + 1, kaq);
       }
       // key halves of the affines for key 16 t + c (rank-1 form of layers.py:705-708), then to the lanes of the D layout
       float co = 0.f, cd = 0.f;
