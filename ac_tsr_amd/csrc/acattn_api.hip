@@ -188,7 +188,7 @@ int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy
 static int check_proj(const acattn_proj_problem* p) {
   if (!p) return fail("problem must be non-NULL");
   if (p->rows < 1) return fail("rows must be positive");
-  if (!acattn_proj_supported(p->H, p->G)) return fail("projections: hidden_size must be 64 and the gate at most 64 wide");
+  if (!acattn_proj_supported(p->H, p->G)) return fail("projections: hidden_size must be 64 and the gate at most 256 wide");
   if (!p->x || !p->wq || !p->bq || !p->wk || !p->bk || !p->wv || !p->bv || !p->waq || !p->baq || !p->wak || !p->bak)
     return fail("projections: input and parameters must be non-NULL");
   if ((p->wg != nullptr) != (p->bg != nullptr) || (p->wg != nullptr) != (p->G > 0))

@@ -44,7 +44,7 @@ template <int DT>
 __device__ __forceinline__ void load_weight(const float* w, int H, int n_out, int c, int g, f4 (&frag)[DT][DT]) {
 #pragma unroll
   for (int nt = 0; nt < DT; ++nt) {
-    const int o = min(16 * nt + c, n_out - 1);  // the gate has seq_length <= 64 outputs: rows past it are never stored
+    const int o = min(16 * nt + c, n_out - 1);
 #pragma unroll
     for (int t = 0; t < DT; ++t) frag[nt][t] = *(const f4*)(w + (size_t)o * H + 16 * t + 4 * g);
   }
@@ -122,24 +122,52 @@ __global__ void __launch_bounds__(64) proj_fwd_kernel(const acattn_proj_problem 
   init_bias<DT, NB>(P.bq, H, g, m);
   product<DT, NB>(wa, xb, m);  // mq
   store_rows<DT, NB>(O.mq, W, g, m);
-  if (P.wg) load_weight<DT>(P.wg, H, P.G, c, g, wa);
   init_bias<DT, NB>(P.baq, H, g, acc);
   product<DT, NB>(wb, m, acc);  // qa = attack_query_transform(mq)
   store_rows<DT, NB>(O.qa, W, g, acc);
   load_weight<DT>(P.wk, H, H, c, g, wb);
   if (P.wg) {
-    init_bias<DT, NB>(P.bg, P.G, g, acc);
-    product<DT, NB>(wa, m, acc);  // gate logits [rows, G]
+    // gate logits [rows, G], G = seq_length (50 ... 200): one 16-wide output tile at a time, the next tile's weight
+    // rows requested before this tile's MFMAs
+    const int GT = (P.G + 15) >> 4;
+    f4 gw[DT], gwn[DT];
+    f4 gb, gbn;
+    auto load_tile = [&](int nt, f4 (&w)[DT], f4& b) {
+      const int o = min(16 * nt + c, P.G - 1);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-      if (W.ok[nb])
+      for (int t = 0; t < DT; ++t) w[t] = *(const f4*)(P.wg + (size_t)o * H + 16 * t + 4 * g);
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+      for (int r = 0; r < 4; ++r) b[r] = P.bg[min(16 * nt + 4 * g + r, P.G - 1)];
+    };
+    load_tile(0, gw, gb);
+    for (int nt = 0; nt < GT; ++nt) {
+      load_tile(nt + 1 < GT ? nt + 1 : nt, gwn, gbn);
+      f4 ga[NB][2];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        ga[nb][0] = gb;
+        ga[nb][1] = f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) ga[nb][r & 1] = mfma16(gw[t][r], m[nb][t][r], ga[nb][r & 1]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const f4 v = ga[nb][0] + ga[nb][1];
+        if (W.ok[nb])
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int j = 16 * t + 4 * g + r;
-            if (j < P.G) O.gate[(size_t)W.row[nb] * P.G + j] = acc[nb][t][r];
+            const int j = 16 * nt + 4 * g + r;
+            if (j < P.G) O.gate[(size_t)W.row[nb] * P.G + j] = v[r];
           }
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t) gw[t] = gwn[t];
+      gb = gbn;
+    }
   }
   load_weight<DT>(P.wak, H, H, c, g, wa);
   init_bias<DT, NB>(P.bk, H, g, m);
@@ -177,17 +205,36 @@ __global__ void __launch_bounds__(64) proj_bwd_kernel(const acattn_proj_problem 
     product<DT, NB>(wa, in, dq);
   }
   if (IO.dgate && P.wg) {
-    load_weight_t<DT>(P.wg, H, P.G, c, g, wa);
+    // d mq += dgate . Wg: the contraction runs over the G gate outputs, 16 at a time
+    const int GT = (P.G + 15) >> 4;
+    f4 gw[DT], gwn[DT];   // A[k = 16nt + c][j = 16 kt + 4g + r] = Wg[j][k]
+    f4 gd[NB], gdn[NB];   // B[j][row]
+    auto load_tile = [&](int kt, f4 (&w)[DT], f4 (&d)[NB]) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * kt + 4 * g + r;
+        const bool in_range = j < P.G;
+        const int jc = in_range ? j : P.G - 1;
 #pragma unroll
-      for (int t = 0; t < DT; ++t)
+        for (int nt = 0; nt < DT; ++nt) w[nt][r] = in_range ? P.wg[(size_t)jc * H + 16 * nt + c] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 16 * t + 4 * g + r;
-          in[nb][t][r] = j < P.G ? IO.dgate[(size_t)W.row[nb] * P.G + j] : 0.f;
-        }
-    product<DT, NB>(wa, in, dq);
+        for (int nb = 0; nb < NB; ++nb) d[nb][r] = in_range ? IO.dgate[(size_t)W.row[nb] * P.G + jc] : 0.f;
+      }
+    };
+    load_tile(0, gw, gd);
+    for (int kt = 0; kt < GT; ++kt) {
+      load_tile(kt + 1 < GT ? kt + 1 : kt, gwn, gdn);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) dq[nb][nt] = mfma16(gw[nt][r], gd[nb][r], dq[nb][nt]);
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) gw[nt] = gwn[nt];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) gd[nb] = gdn[nb];
+    }
   }
   if (IO.dmq_total) store_rows<DT, NB>(IO.dmq_total, W, g, dq);
   if (IO.dx) {
@@ -219,7 +266,7 @@ int rows_per_wave(int rows) { return rows >= 16384 ? 32 : 16; }
 
 }  // namespace
 
-bool acattn_proj_supported(int H, int G) { return H == 64 && G >= 0 && G <= 64; }
+bool acattn_proj_supported(int H, int G) { return H == 64 && G >= 0 && G <= 256; }
 
 int acattn_launch_proj_fwd(const acattn_proj_problem& p, const acattn_proj_out& o, hipStream_t stream) {
   const int rpw = rows_per_wave(p.rows), blocks = (p.rows + rpw - 1) / rpw;

@@ -344,7 +344,7 @@ int acattn_select_layer_tail_blocks(int nb);
  *     mq, mk, mv = query(x), key(x), value(x)                               recbole/model/layers.py:687-689
  *     qa, ka     = attack_query_transform(mq), attack_key_transform(mk)     recbole/model/layers.py:658-659
  *     gate       = gate(mq)  [rows, G], G = seq_length                      recbole/model/layers.py:887
- * hidden_size 64, G <= 64; weights are the row-major nn.Linear parameters ([out, in]). */
+ * hidden_size 64, G <= 256; weights are the row-major nn.Linear parameters ([out, in]). */
 typedef struct acattn_proj_problem {
   int32_t rows, H, G;        /* G = 0 and wg = bg = NULL without the gate (combine_option != 'gate') */
   const float* x;            /* [rows,H] the layer's input */

@@ -94,7 +94,7 @@ def test_validation_errors_without_gpu(lib):
     assert lib.acattn_layer_tail_fwd(C.byref(tp), C.byref(ts), None) < 0 and b"hidden_size" in lib.acattn_last_error()
     assert lib.acattn_layer_tail_supported(64, 256) == 1 and lib.acattn_layer_tail_supported(128, 256) == 0
     pp, po = _lib.ProjProblem(), _lib.ProjOut()
-    pp.rows, pp.H, pp.G = 16, 64, 80
+    pp.rows, pp.H, pp.G = 16, 64, 300
     assert lib.acattn_projections_fwd(C.byref(pp), C.byref(po), None) < 0 and b"gate" in lib.acattn_last_error()
     assert lib.acattn_projections_supported(64, 50) == 1 and lib.acattn_projections_supported(128, 50) == 0
 

@@ -42,7 +42,7 @@ def _reference(t, G):
     return d, out
 
 
-@pytest.mark.parametrize("rows,G", [(512, 50), (37, 50), (16384 + 21, 50), (100, 0), (64, 64), (48, 37)])
+@pytest.mark.parametrize("rows,G", [(512, 50), (37, 50), (16384 + 21, 50), (100, 0), (64, 64), (48, 37), (200, 200), (16400, 130)])
 def test_fused_projections_match_fp64_linears(rows, G):
     H = 64
     t, cot = _inputs(rows, H, G, seed=rows + G)
