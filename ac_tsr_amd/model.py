@@ -8,6 +8,8 @@ state-dict keys.  `config[k]` may be any mapping; missing keys read as None like
 """
 from __future__ import annotations
 
+import logging
+
 import random
 from enum import Enum
 
@@ -393,6 +395,15 @@ class AcBERT4Rec(SequentialRecommender):
             per_slot = ce.full_sort_cross_entropy_rows(rows, table, pos_items.reshape(-1), table_grad=not attack_loss,
                                                        state=self.step_state)
         else:
+            # hidden sizes the fused cross-entropy does not cover (256): materialised [rows, N] logits.  A deliberate
+            # choice for this model, not an omission: with ~20k masked slots per batch a recompute-based fused CE costs
+            # 5 catalogue products against 3, and the logits (1.6 GB at 20k x 20k) are < 1 % of the 288 GB of HBM
+            # (DESIGN.md section 8); said once per process so that nobody has to find it in a profile.
+            if rows.is_cuda and not getattr(AcBERT4Rec, "_noted_materialised_ce", False):
+                AcBERT4Rec._noted_materialised_ce = True
+                logging.getLogger("ac_tsr_amd").info(
+                    "AcBERT4Rec: hidden_size %d is outside the fused cross-entropy (64, 128); the masked-slot CE uses "
+                    "materialised [%d, %d] logits", self.hidden_size, rows.shape[0], table.shape[0])
             per_slot = nn.functional.cross_entropy(full_sort_scores(rows, table, self.step_state), pos_items.reshape(-1),
                                                    reduction='none')
         return torch.sum(per_slot * targets) / torch.sum(targets)
