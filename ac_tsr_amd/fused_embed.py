@@ -57,13 +57,14 @@ class _EmbedLayerNorm(torch.autograd.Function):
                               keep if keep is not None else empty, seed_tensor if seed_tensor is not None else empty)
         ctx.args = (eps, p_drop, pos is not None, keep is not None, seed, seed_tensor is not None, padding_idx)
         ctx.mark_non_differentiable(nonzero)
+        ctx.set_materialize_grads(False)  # no zero-filled "gradient" of the validity bytes (one launch per backward)
         return y, nonzero
 
     @staticmethod
     def backward(ctx, dy, _d_nonzero=None):
         idx, table, pos, gamma, beta, stats, keep, seed_tensor = ctx.saved_tensors
         eps, p_drop, has_pos, has_keep, seed, has_seed_t, padding_idx = ctx.args
-        if ctx.state.attack_pass_only:  # none of these parameters is an attack transform (trainer.py:678-684)
+        if ctx.state.attack_pass_only or dy is None:  # none of these parameters is an attack transform (trainer.py:678-684)
             return (None,) * 12
         lib = _lib.load()
         p = _problem(idx, table, pos if has_pos else None, gamma, beta, eps, p_drop, keep if has_keep else None, seed,
