@@ -163,7 +163,7 @@ class AcattnError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libacattn.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    jobs = str(min(4, os.cpu_count() or 1))
+    jobs = str(min(8, os.cpu_count() or 1))
     res = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=not verbose, text=True)
     if res.returncode != 0:
         raise AcattnError("building libacattn.so failed:\n" + (res.stdout or "") + (res.stderr or ""))
