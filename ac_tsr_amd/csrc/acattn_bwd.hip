@@ -21,10 +21,19 @@ int acattn_bwd_kernel_choice(int which) {
 
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
   // training hot paths (structured mask, counter RNG, gate, two_level), -100 = not applicable:
-  //   streaming two-kernel backward (acattn_bwd_stream.hip; needs io.workspace): the default.  B = 512, all three
-  //   cotangents: L = 50 57 + 41 us against 131 us row-resident; L = 200 (H = 128, 4 heads) 0.87 ms against 7.0 ms;
-  //   row-resident kernel, one recomputation (acattn_bwd_fast.hip, L <= 64): ACATTN_BWD_ROW, or no workspace
+  //   L <= 64: the row-resident kernel (acattn_bwd_fast.hip, one recomputation, a query block's row in registers).
+  //     Inside the training step at B = 512, L = 50 its four calls take 71 / 108 / 103 / 57 us against 80 / 112 / 110 /
+  //     92 us of the streaming pair (same box, same step: 1.76 against 1.81 ms per step); the attack-only call
+  //     (dqa, dka alone) gains most.  In isolation with all three cotangents the order was the other way round
+  //     (57 + 41 against 131 us) before the common random-number / mask code got cheaper for both.
+  //   L > 64, or ACATTN_BWD_STREAM: the streaming two-kernel backward (acattn_bwd_stream.hip; needs io.workspace):
+  //     L = 200 (H = 128, 4 heads) 0.87 ms against 7.0 ms of the general kernel.
   const int which = g_bwd_kernel;
+  const bool short_rows = p.L <= 64;
+  if (which == ACATTN_BWD_AUTO && short_rows) {
+    const int rc_fast = acattn_launch_bwd_fast(p, io, stream);
+    if (rc_fast != -100) return rc_fast;
+  }
   if (which == ACATTN_BWD_AUTO || which == ACATTN_BWD_STREAM) {
     const int rc_stream = acattn_launch_bwd_stream(p, io, stream);
     if (rc_stream != -100) return rc_stream;

@@ -237,7 +237,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    # A process that starts while the previous GPU process of the same box is still being torn down has (rarely: 2 of
+    # ~40 back-to-back launches) found no device; wait for the device before doing anything, then fail loudly.
+    for _ in range(10):
+        if torch.cuda.is_available():
+            break
+        time.sleep(1.0)
+    else:
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # Rehearsal on a box with fewer GPUs than ranks (the 8-GPU run is the driver's): ACATTN_BENCH_REHEARSAL=1 puts every
     # rank on cuda:0 and uses gloo for the collectives.  Exercises the launch / barrier / two-graph / early-reduce path;

@@ -418,7 +418,7 @@ int acattn_select_forward_kernel(int which);
 
 /* The same for acattn_calibrated_attention_bwd. */
 enum {
-  ACATTN_BWD_AUTO = 0,    /* streaming where it applies (training configuration, io.workspace given), else row-resident */
+  ACATTN_BWD_AUTO = 0,    /* training configuration: row-resident for L <= 64, streaming (io.workspace given) beyond */
   ACATTN_BWD_STREAM = 1,  /* acattn_bwd_stream.hip: row kernel + key kernel, tiles rebuilt from the saved normalisers */
   ACATTN_BWD_ROW = 2      /* acattn_bwd_fast.hip / acattn_bwd.hip: a query block's whole row in registers */
 };
