@@ -275,7 +275,7 @@ def main():
     if a.kernel_only:
         out = {"roofline": kernel_roofline(a, device, True, a.kernel_iters),
                "roofline_spatial_only": kernel_roofline(a, device, False, a.kernel_iters)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
         return
 
     torch.manual_seed(42)  # config/*.yaml seed: 42 -- identical initial parameters on every rank
@@ -369,10 +369,22 @@ def main():
             res["cpu_baseline"] = cpu_baseline(a, init_state, a.cpu_steps)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        # flushed at once: stdout is a pipe or a file here (block-buffered), and a line still sitting in the buffer is
+        # lost if anything goes wrong while the process is being torn down (3 of ~60 runs in this round ended with an
+        # empty stdout; none of the 50 runs whose stderr was kept did)
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # release the captured graphs and everything they hold before the interpreter starts tearing modules down
+    try:
+        del full_trainer
+    except NameError:
+        pass
+    del trainer, sync, model, pool
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":
