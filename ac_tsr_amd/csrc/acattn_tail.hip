@@ -45,7 +45,7 @@ int acattn_tail_bwd_partial_rows(int rows);
 
 namespace {
 
-int g_tail_nb = 0;  // rows per wave / 16; 0 = by size (measurement hook: acattn_select_layer_tail_blocks)
+int g_tail_nb = getenv("ACATTN_TAIL_BLOCKS") ? atoi(getenv("ACATTN_TAIL_BLOCKS")) : 0;  // rows per wave / 16; 0 = by size (measurement hooks: this and acattn_select_layer_tail_blocks)
 // four waves per row block while one wave per block would leave most SIMDs without work
 bool split_slabs(int rows) {
   static const int limit = getenv("ACATTN_TAIL_SPLIT_ROWS") ? atoi(getenv("ACATTN_TAIL_SPLIT_ROWS")) : 4096;
