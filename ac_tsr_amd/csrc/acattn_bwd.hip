@@ -9,6 +9,7 @@ int acattn_launch_bwd_general_dh128(const acattn_problem& p, const acattn_bwd_io
 
 int acattn_launch_bwd_fast(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
 int acattn_launch_bwd_stream(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
+int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
 
 namespace {
 int g_bwd_kernel = ACATTN_BWD_AUTO;
@@ -29,6 +30,10 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
   //   L > 64, or ACATTN_BWD_STREAM: the streaming two-kernel backward (acattn_bwd_stream.hip; needs io.workspace):
   //     L = 200 (H = 128, 4 heads) 0.87 ms against 7.0 ms of the general kernel.
   const int which = g_bwd_kernel;
+  if (which == ACATTN_BWD_AUTO) {  // one position per sequence carries a cotangent: one row of the backward (any L)
+    const int rc_one = acattn_launch_bwd_onerow(p, io, stream);
+    if (rc_one != -100) return rc_one;
+  }
   const bool short_rows = p.L <= 64;
   if (which == ACATTN_BWD_AUTO && short_rows) {
     const int rc_fast = acattn_launch_bwd_fast(p, io, stream);

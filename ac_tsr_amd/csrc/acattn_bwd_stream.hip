@@ -79,23 +79,13 @@ struct Tile {
   int eb[4];        // -1 where the key may receive probability mass
 };
 
-template <int DH>
-__device__ __forceinline__ void tile_forward(const Row<DH>& R, const Consts& K, const f4 (&k4)[DH / 16], const f4 (&ka4)[DH / 16],
-                                             const f4 (&v4)[DH / 16], const f4 co4, const f4 cd4, const f4 gl, const int t,
-                                             const int g, const uint32_t eb4, const uint32_t ab4, const bool order_select,
-                                             Tile& T) {
-  constexpr int KS = DH / 4;
-  f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS, aP = aS, aW = aS;
-#pragma unroll
-  for (int s4 = 0; s4 < KS / 4; ++s4) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      aS = mfma16(k4[s4][e], R.qf[4 * s4 + e], aS);
-      aM = mfma16(ka4[s4][e], R.qaf[4 * s4 + e], aM);
-      aP = mfma16(v4[s4][e], R.gaf[4 * s4 + e], aP);
-      aW = mfma16(v4[s4][e], R.gcf[4 * s4 + e], aW);
-    }
-  }
+// Everything of tile_forward that follows the four products (raw scores S, Sa and the cotangents dA_p, dA_w of the
+// lane's 4 keys): RowT supplies the row's scalars (Row<DH>, or RowScalars of the one-row kernel).
+template <class RowT>
+__device__ __forceinline__ void tile_elementwise(const RowT& R, const Consts& K, const f4 aS, const f4 aM, const f4 aP,
+                                                 const f4 aW, const f4 co4, const f4 cd4, const f4 gl, const int t,
+                                                 const int g, const uint32_t eb4, const uint32_t ab4,
+                                                 const bool order_select, Tile& T) {
   T.dAp = aP;
   T.dAw = aW;
   const f4 ea = co4 + R.ao2;
@@ -151,6 +141,26 @@ __device__ __forceinline__ void tile_forward(const Row<DH>& R, const Consts& K, 
   const f4 aw = (T.gt * (T.P - T.Ac) + T.Ac) * kLog2e - R.lw2;  // layers.py:888, 925
 #pragma unroll
   for (int r = 0; r < 4; ++r) T.Aw[r] = and_bits(ex2(aw[r]), T.eb[r]);
+}
+
+template <int DH>
+__device__ __forceinline__ void tile_forward(const Row<DH>& R, const Consts& K, const f4 (&k4)[DH / 16], const f4 (&ka4)[DH / 16],
+                                             const f4 (&v4)[DH / 16], const f4 co4, const f4 cd4, const f4 gl, const int t,
+                                             const int g, const uint32_t eb4, const uint32_t ab4, const bool order_select,
+                                             Tile& T) {
+  constexpr int KS = DH / 4;
+  f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS, aP = aS, aW = aS;
+#pragma unroll
+  for (int s4 = 0; s4 < KS / 4; ++s4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      aS = mfma16(k4[s4][e], R.qf[4 * s4 + e], aS);
+      aM = mfma16(ka4[s4][e], R.qaf[4 * s4 + e], aM);
+      aP = mfma16(v4[s4][e], R.gaf[4 * s4 + e], aP);
+      aW = mfma16(v4[s4][e], R.gcf[4 * s4 + e], aW);
+    }
+  }
+  tile_elementwise(R, K, aS, aM, aP, aW, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
 }
 
 // Backward part once the row scalars are known: dS, dSa (scores), the gate-logit gradient, d o and d d of the two
@@ -673,6 +683,200 @@ __global__ void __launch_bounds__(64, 2) acattn_bwd_key_kernel(const acattn_prob
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// one-row kernel
+// ---------------------------------------------------------------------------------------------------------------------
+// The last layer is read at ONE position per sequence (item_seq_len - 1, abstract_recommender.py:130-134), so in the
+// calibrated-loss pass its context cotangents are zero everywhere but in that row: of the L x L backward only one row
+// of every probability tensor matters.  One wave per (sequence, head): lane l owns keys 4 l .. 4 l + 3 of that row
+// (the lane's 4 keys of tile_elementwise / tile_backward, with t = l / 4, g = l % 4 -- the same code, the same random
+// draws), the four products of a key are plain dot products against row vectors kept in LDS, the row sums are wave
+// reductions.  Every output is written in full (rows other than the read one are zero), so the caller needs no fill.
+struct RowScalars {
+  float ao2, ad, lx2, ly2, lu2, lv2, lw2;
+  int i;
+  uint32_t rng_row;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int DH>
+__global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_problem P, const acattn_bwd_io IO) {
+  constexpr int D4 = DH / 4;
+  __shared__ __attribute__((aligned(16))) float vec[8][DH];  // q, qa, d_ctx_att, d_ctx_cal, wko, wkd, w_order_q, w_dist_q
+  __shared__ __attribute__((aligned(16))) float col[4][256];  // dS, dSa, d_o, d_d of every key
+  const int L = P.L, H = P.H, nh = P.n_heads;
+  const int nT = (L + 15) >> 4;
+  const bool causal = P.causal != 0;
+  int b, h;
+  decode_block(blockIdx.x, P.B, nh, b, h);
+  const int lane = threadIdx.x;
+  const size_t rowbase = (size_t)b * L, bh = (size_t)b * nh + h;
+  const int hoff = h * DH;
+  const int i = (int)IO.read_rows[b];  // n_read_rows == 1
+  const KeyFlags F = load_key_flags(P.key_valid, rowbase, L, nT, lane);
+  const Consts K = make_consts(P, DH);
+
+  // ---- the row's vectors ----------------------------------------------------------------------------------------------
+  for (int d = lane; d < DH; d += 64) {
+    const size_t o = (rowbase + i) * H + hoff + d;
+    vec[0][d] = P.q[o];
+    vec[1][d] = P.qa[o];
+    vec[2][d] = IO.d_ctx_attacked ? IO.d_ctx_attacked[o] : 0.f;
+    vec[3][d] = IO.d_ctx_calibrated ? IO.d_ctx_calibrated[o] : 0.f;
+    vec[4][d] = P.w_order[DH + d] * -kLog2e;
+    vec[5][d] = P.w_dist[DH + d];
+    vec[6][d] = P.w_order[d];
+    vec[7][d] = P.w_dist[d];
+  }
+  __syncthreads();
+  RowScalars R;
+  {
+    float ao = 0.f, adv = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      ao += vec[0][d] * vec[6][d];
+      adv += vec[0][d] * vec[7][d];
+    }
+    R.ao2 = -kLog2e * (ao + P.b_order[0]);
+    R.ad = adv + P.b_dist[0];
+  }
+  const bool dead = causal ? F.first_valid > i : !F.any_valid;
+  {
+    const float sh = dead ? ACATTN_MASK_FILL : 0.f;
+    const float* sp = IO.row_stats + (bh * L + i) * ACATTN_NSTAT;
+    R.lx2 = (sp[0] - sh) * kLog2e;
+    R.ly2 = (sp[1] - sh) * kLog2e;
+    R.lu2 = (sp[2] - sh) * kLog2e;
+    R.lv2 = (sp[3] - sh) * kLog2e;
+    R.lw2 = (sp[4] - sh) * kLog2e;
+  }
+  R.i = i;
+  R.rng_row = (uint32_t)(bh * L + i);
+  const bool order_select = !causal || dead;
+
+  // ---- the lane's 4 keys: S, Sa, dA_p, dA_w and the key halves of the affines as dot products ---------------------------
+  const int t = lane >> 2, g = lane & 3, j0 = 4 * lane;
+  f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS, aP = aS, aW = aS, co4 = aS, cd4 = aS;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const size_t o = (rowbase + min(j0 + r, L - 1)) * H + hoff;
+#pragma unroll 2
+    for (int d4 = 0; d4 < D4; ++d4) {
+      const f4 kv = *(const f4*)(P.k + o + 4 * d4), kav = *(const f4*)(P.ka + o + 4 * d4), vv = *(const f4*)(P.v + o + 4 * d4);
+      const f4 q4 = *(const f4*)(&vec[0][4 * d4]), qa4 = *(const f4*)(&vec[1][4 * d4]);
+      const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
+      const f4 wo4 = *(const f4*)(&vec[4][4 * d4]), wd4 = *(const f4*)(&vec[5][4 * d4]);
+      aS[r] += hsum(kv * q4);
+      aM[r] += hsum(kav * qa4);
+      aP[r] += hsum(vv * ga4);
+      aW[r] += hsum(vv * gc4);
+      co4[r] += hsum(kv * wo4);
+      cd4[r] += hsum(kv * wd4);
+    }
+  }
+  const f4 gl = load_seg(P.gate_logits + (rowbase + i) * L, j0, L, true);
+  uint32_t eb4, ab4;
+  tile_bits(F, t, g, i, L, causal, true, dead, eb4, ab4);
+  if (j0 >= 16 * nT) eb4 = 0u;  // lanes past the last key tile
+  Tile T;
+  tile_elementwise(R, K, aS, aM, aP, aW, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+
+  // ---- row scalars of the chained soft-max backward (section 4.2 of DESIGN.md, directly: the row is in registers) ----------
+  const float da = wave_sum(hsum(T.Ap * T.dAp)), dc = wave_sum(hsum(T.Aw * T.dAw));
+  const f4 dw = T.Aw * (T.dAw - dc);
+  const f4 dac = (1.0f - T.gt) * dw;
+  const float r1 = wave_sum(hsum(T.Ac * dac));
+  const f4 du = T.Ap * (T.dAp - da), dv = T.Ac * (dac - r1);
+  f4 dP = T.gt * dw + dv * T.ex1 + du * T.M;
+  f4 dM = du * (T.P - T.nz) - dv * (T.P * T.ex1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    dP[r] = keep_and(dP[r] * K.keep_scale, T.ka, r);
+    dM[r] = keep_and(dM[r] * K.keep_scale, T.km, r);
+  }
+  const float sP = wave_sum(hsum(T.Pt * dP)), sM = wave_sum(hsum(T.Mt * dM));
+  f4 dS, dSa, dgl, d_o, d_d;
+  float dsc;
+  tile_backward(T, K, da, dc, r1, sP, sM, f4{0.f, 0.f, 0.f, 0.f}, i, j0, dS, dSa, dgl, d_o, d_d, dsc);
+  const float da_o = wave_sum(hsum(d_o)), da_d = wave_sum(hsum(d_d)), dsc_sum = wave_sum(dsc);
+  *(f4*)(&col[0][j0]) = dS;
+  *(f4*)(&col[1][j0]) = dSa;
+  *(f4*)(&col[2][j0]) = d_o;
+  *(f4*)(&col[3][j0]) = d_d;
+
+  // ---- key side: dk, dka, dv of the lane's 4 keys (rank one in the row's vectors) ------------------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = j0 + r;
+    if (j < L) {
+      const size_t o = (rowbase + j) * H + hoff;
+#pragma unroll 2
+      for (int d4 = 0; d4 < D4; ++d4) {
+        const f4 q4 = *(const f4*)(&vec[0][4 * d4]), qa4 = *(const f4*)(&vec[1][4 * d4]);
+        const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
+        const f4 wo_hi = *(const f4*)(P.w_order + DH + 4 * d4), wd_hi = *(const f4*)(P.w_dist + DH + 4 * d4);
+        *(f4*)(IO.dk + o + 4 * d4) = q4 * dS[r] + wo_hi * d_o[r] + wd_hi * d_d[r];
+        *(f4*)(IO.dka + o + 4 * d4) = qa4 * dSa[r];
+        *(f4*)(IO.dv + o + 4 * d4) = ga4 * T.Ap[r] + gc4 * T.Aw[r];
+      }
+    }
+  }
+  // ---- gate-logit gradient: the read row carries dgl, every other row is zero --------------------------------------------------
+  if (IO.dgate_logits) {
+    float* gbase = IO.dgate_logits + bh * (size_t)L * L;
+    for (int row = 0; row < L; ++row) {
+      if (row == i) continue;
+      for (int j = lane; j < L; j += 64) gbase[(size_t)row * L + j] = 0.f;
+    }
+    store_seg(gbase + (size_t)i * L, j0, L, true, dgl);
+  }
+  __syncthreads();  // col[] complete
+
+  // ---- query side and key halves of the parameter gradients: lane d sums over the keys --------------------------------------
+  const int stride_w = IO.part_stride ? IO.part_stride : 2 * DH, stride_s = IO.part_stride ? IO.part_stride : 4;
+  for (int d = lane; d < DH; d += 64) {
+    float sq = 0.f, sqa = 0.f, so = 0.f, sd = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const size_t o = (rowbase + j) * H + hoff + d;
+      const float kv = P.k[o], kav = P.ka[o];
+      sq += col[0][j] * kv;
+      sqa += col[1][j] * kav;
+      so += col[2][j] * kv;
+      sd += col[3][j] * kv;
+    }
+    // every row of dq / dqa but the read one is zero
+    for (int row = 0; row < L; ++row) {
+      const size_t o = (rowbase + row) * H + hoff + d;
+      IO.dq[o] = row == i ? sq + da_o * vec[6][d] + da_d * vec[7][d] : 0.f;
+      IO.dqa[o] = row == i ? sqa : 0.f;
+    }
+    IO.dw_order_part[bh * stride_w + d] = da_o * vec[0][d];
+    IO.dw_dist_part[bh * stride_w + d] = da_d * vec[0][d];
+    IO.dw_order_part[bh * stride_w + DH + d] = so;
+    IO.dw_dist_part[bh * stride_w + DH + d] = sd;
+  }
+  if (lane == 0) {
+    float* sm = IO.dsmall_part + bh * stride_s;
+    sm[0] = da_o;
+    sm[1] = da_d;
+    sm[2] = dsc_sum;
+    sm[3] = 0.f;
+  }
+}
+
+// Returns -100 when the one-row form does not apply.
+template <int DH>
+int launch_onerow(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
+  hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH>), dim3(p.B * p.n_heads), dim3(64), 0, stream, p, io);
+  return (int)hipGetLastError();
+}
+
 template <int DH>
 int launch_stream(const acattn_problem& p, const acattn_bwd_io& io, float* ws, hipStream_t stream) {
   const int nT = (p.L + 15) / 16, dh = DH;
@@ -696,6 +900,23 @@ int launch_stream(const acattn_problem& p, const acattn_bwd_io& io, float* ws, h
 }  // namespace
 
 int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p) { return (int64_t)p.B * p.n_heads * p.L * NSC * sizeof(float); }
+
+// The calibrated-loss pass through the LAST layer: only the read position of every sequence carries a cotangent
+// (io.read_rows with one position per sequence, no mask cotangent).  Returns -100 when that is not the situation.
+int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
+  static const bool enabled = getenv("ACATTN_ONEROW") ? atoi(getenv("ACATTN_ONEROW")) != 0 : true;
+  const bool ok = enabled && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.d_attack_mask && !io.attack_only &&
+                  p.L <= 208 && (int64_t)p.B * p.n_heads * p.L * p.L < (1LL << 30) && (int64_t)p.B * p.L * p.H < (1LL << 30) &&
+                  p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order && p.w_dist &&
+                  p.adversarial && p.combine_option == ACATTN_COMBINE_GATE && p.two_level;
+  if (!ok) return -100;
+  switch (p.H / p.n_heads) {
+    case 16: return launch_onerow<16>(p, io, stream);
+    case 32: return launch_onerow<32>(p, io, stream);
+    case 64: return launch_onerow<64>(p, io, stream);
+  }
+  return -100;
+}
 
 // Returns -100 when the problem is outside this path's domain (the caller then uses the row-resident kernels).
 int acattn_launch_bwd_stream(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
