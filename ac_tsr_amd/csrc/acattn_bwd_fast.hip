@@ -265,8 +265,14 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     }
   };
 
-  auto body = [&](auto ntb_c) {
+  // MASK_ONLY: a query block none of whose rows carries a CONTEXT cotangent while the attack mask does carry one (the
+  // attacked-loss pass through the last layer: the context is read at one position per sequence, the mask penalty
+  // reaches every row).  With dA_p = dA_w = 0 every term of the chain vanishes except the soft-max of the mask scores:
+  //     dSa = Mt (keep . dM_out - sum_j Mt keep dM_out) / sqrt(dh)  ->  dqa, dka;   dq = dk = dv = dgate = 0
+  // so such a block forms Sa only: no spatial calibrator, no noise, none of the five exponentials of the other branches.
+  auto body = [&](auto ntb_c, auto mask_only_c) {
     constexpr int NTB = decltype(ntb_c)::value;
+    constexpr bool MASK_ONLY = decltype(mask_only_c)::value;
 
     // transposes a register tile set through the wave's scratch and accumulates
     //   acc[key][d] += sum_i tile[i][key] * rows[i][d]      (LDS float atomics; rows read from global / L2)
@@ -317,31 +323,42 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
 
     // ---- phase 0: Pt, Mt ------------------------------------------------------------------------------------
     f4 tS[NTB], tM[NTB];
-    score_tiles(Ks, qf, tS);
+    if constexpr (!MASK_ONLY) score_tiles(Ks, qf, tS);
     score_tiles(Kas, qaf, tM);
 #pragma unroll
     for (int t = 0; t < NTB; ++t) {
-      f4 pr, val, df;
-      spatial(t, pr, val, df);
       const f4 mk4 = mask4(t);
-      f4 lg;
+      if constexpr (!MASK_ONLY) {
+        f4 pr, val, df;
+        spatial(t, pr, val, df);
+        f4 lg;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lg[r] = __builtin_amdgcn_logf(val[r] + ACATTN_LOG_EPS);
-      f4 x = tS[t] * scale2 + mk4;
-      x = lg * inv_sqrt + x;
-      x = (df * df) * nc2 + x;
+        for (int r = 0; r < 4; ++r) lg[r] = __builtin_amdgcn_logf(val[r] + ACATTN_LOG_EPS);
+        f4 x = tS[t] * scale2 + mk4;
+        x = lg * inv_sqrt + x;
+        x = (df * df) * nc2 + x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tS[t][r] = ex2(x[r] - lse_x2) * okf;
+      }
       const f4 y = tM[t] * scale2 + mk4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        tS[t][r] = ex2(x[r] - lse_x2) * okf;
-        tM[t][r] = ex2(y[r] - lse_y2) * okf;
-      }
+      for (int r = 0; r < 4; ++r) tM[t][r] = ex2(y[r] - lse_y2) * okf;
     }
 
     // ---- phase 1: perturbed branch ---------------------------------------------------------------------------
     f4 dPa[NTB], dMa[NTB];
     uint32_t keepA = 0, keepM = 0;  // dropout keep bits, 4 per tile
-    {
+    if constexpr (MASK_ONLY) {
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) {
+        const RngGroup rg = rng_group(rkey, rng_row, (uint32_t)(4 * t + g), P.p_drop);
+        keepM |= (has_drop ? rg.keep_mask : 0xFu) << (4 * t);
+        dMa[t] = f4{0.f, 0.f, 0.f, 0.f};
+        dPa[t] = dMa[t];
+      }
+      if (full)
+        for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, f4{0.f, 0.f, 0.f, 0.f});
+    } else {
       f4 dAp[NTB], Ap[NTB], nz[NTB];
       float gaf[KS];
       row_frag(IO.d_ctx_attacked, gaf);
@@ -379,7 +396,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     }
 
     // ---- phase 2: calibrated branch ----------------------------------------------------------------------------
-    {
+    if constexpr (!MASK_ONLY) {
       f4 dAw[NTB], Ac[NTB], Aw[NTB];
       float gcf[KS];
       row_frag(IO.d_ctx_calibrated, gcf);
@@ -467,16 +484,19 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         sm[r] = ((keepM >> (4 * t + r)) & 1u) ? keep_scale : 0.f;
       }
       dMa[t] *= sm;
-      dPa[t] *= sa;
       r2 += hsum(tM[t] * dMa[t]);
-      r3 += hsum(tS[t] * dPa[t]);
+      if constexpr (!MASK_ONLY) {
+        dPa[t] *= sa;
+        r3 += hsum(tS[t] * dPa[t]);
+      }
     }
     r2 = quad_sum(r2);
-    r3 = quad_sum(r3);
+    if constexpr (!MASK_ONLY) r3 = quad_sum(r3);
     float da_o = 0.f, da_d = 0.f, dsc = 0.f;
 #pragma unroll
     for (int t = 0; t < NTB; ++t) {
       dMa[t] = (tM[t] * (dMa[t] - r2)) * inv_sqrt;  // dSa
+      if constexpr (MASK_ONLY) continue;
       dPa[t] = (tS[t] * (dPa[t] - r3)) * inv_sqrt;  // dS (the calibrator terms are additive)
       f4 pr, val, df;
       spatial(t, pr, val, df);
@@ -502,15 +522,17 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     da_o = quad_sum(da_o);
     da_d = quad_sum(da_d);
     dsc = quad_sum(dsc);
+    if constexpr (!MASK_ONLY) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float vo = row16_sum(da_o * qf[s]), vd = row16_sum(da_d * qf[s]);
-      if (c == 0) {
-        atomicAdd(s_dwq + KS * g + s, vo);
-        atomicAdd(s_dwq + DH + KS * g + s, vd);
+      for (int s = 0; s < KS; ++s) {
+        const float vo = row16_sum(da_o * qf[s]), vd = row16_sum(da_d * qf[s]);
+        if (c == 0) {
+          atomicAdd(s_dwq + KS * g + s, vo);
+          atomicAdd(s_dwq + DH + KS * g + s, vd);
+        }
       }
     }
-    {
+    if constexpr (!MASK_ONLY) {
       const float so = row16_sum(da_o), sd = row16_sum(da_d), ss = row16_sum(dsc);  // totals over the 16 rows
       if (lane == 0) {
         atomicAdd(s_small + 0, so);
@@ -535,7 +557,8 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
           const float* kap = Kas + (16 * t + 4 * g + r) * VS + c;
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            if (full) oq[dt] = mfma16(kp[16 * dt], dPa[t][r], oq[dt]);
+            if constexpr (!MASK_ONLY)
+              if (full) oq[dt] = mfma16(kp[16 * dt], dPa[t][r], oq[dt]);
             oqa[dt] = mfma16(kap[16 * dt], dMa[t][r], oqa[dt]);
           }
         }
@@ -550,7 +573,8 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         }
       }
     }
-    if (full) key_side(dPa, P.q, aK);
+    if constexpr (!MASK_ONLY)
+      if (full) key_side(dPa, P.q, aK);
     key_side(dMa, P.qa, aKa);
   };
 
@@ -558,12 +582,19 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   // the caller expects in dq, dqa and the gate partials (the last layer of the models is read at one position per
   // sequence, so three of its four blocks are such blocks in the calibrated-loss pass).
   const bool block_active = qblock_active(IO, b, qb);
-  if (block_active) {
+  if (block_active && !qblock_has_ctx(IO, b, qb)) {  // only the mask cotangent reaches this block
     switch (nt) {
-      case 1: body(std::integral_constant<int, 1>{}); break;
-      case 2: body(std::integral_constant<int, 2>{}); break;
-      case 3: body(std::integral_constant<int, 3>{}); break;
-      default: body(std::integral_constant<int, 4>{}); break;
+      case 1: body(std::integral_constant<int, 1>{}, std::true_type{}); break;
+      case 2: body(std::integral_constant<int, 2>{}, std::true_type{}); break;
+      case 3: body(std::integral_constant<int, 3>{}, std::true_type{}); break;
+      default: body(std::integral_constant<int, 4>{}, std::true_type{}); break;
+    }
+  } else if (block_active) {
+    switch (nt) {
+      case 1: body(std::integral_constant<int, 1>{}, std::false_type{}); break;
+      case 2: body(std::integral_constant<int, 2>{}, std::false_type{}); break;
+      case 3: body(std::integral_constant<int, 3>{}, std::false_type{}); break;
+      default: body(std::integral_constant<int, 4>{}, std::false_type{}); break;
     }
   } else if (row_ok) {
     const f4 z = {0.f, 0.f, 0.f, 0.f};

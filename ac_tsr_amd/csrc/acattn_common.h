@@ -182,6 +182,17 @@ __device__ __forceinline__ void store_out1(float* p, const float v) { __builtin_
 // of one sequence are placed 8 blocks apart: they read the same gate-logit tile from one L2.
 // Pure speed hint; any placement gives the same results.
 // Does query block qb of sequence b carry a non-zero context cotangent?  (acattn_bwd_io.active_qblocks / read_rows)
+// Does some row of query block qb of sequence b carry a non-zero CONTEXT cotangent (d_ctx_*)?
+__device__ __forceinline__ bool qblock_has_ctx(const acattn_bwd_io& IO, int b, int qb) {
+  if (IO.active_qblocks) return (IO.active_qblocks[b] >> qb) & 1u;
+  if (IO.read_rows) {
+    for (int r = 0; r < IO.n_read_rows; ++r)
+      if ((int)(IO.read_rows[(size_t)b * IO.n_read_rows + r] >> 4) == qb) return true;
+    return false;
+  }
+  return true;
+}
+
 __device__ __forceinline__ bool qblock_active(const acattn_bwd_io& IO, int b, int qb) {
   if (IO.d_attack_mask) return true;  // the mask cotangent reaches every row
   if (IO.active_qblocks) return (IO.active_qblocks[b] >> qb) & 1u;

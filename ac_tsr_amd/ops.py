@@ -252,9 +252,10 @@ class _CalibratedAttention(torch.autograd.Function):
         base = part.data_ptr()
         io.dw_order_part, io.dw_dist_part, io.dsmall_part = base, base + 4 * 2 * dh, base + 4 * 4 * dh
         io.part_stride = width
-        # the hint is only valid when the mask cotangent (which reaches every row) is absent
-        io.active_qblocks = _ptr(ctx.active_qblocks) if (ctx.active_qblocks is not None and d_M is None) else None
-        if ctx.read_rows is not None and d_M is None:
+        # the context cotangents are zero outside the read positions (the caller's promise, `read_rows`)
+        # (with a mask cotangent every block stays active, but those without a read position only owe the mask path)
+        io.active_qblocks = _ptr(ctx.active_qblocks) if ctx.active_qblocks is not None else None
+        if ctx.read_rows is not None:
             io.read_rows, io.n_read_rows = _ptr(ctx.read_rows), ctx.read_rows.shape[1]
         # pass 2 through a layer with nothing attack-related upstream: only the attack transforms' inputs matter
         attack_only = ctx.state.attack_pass_only and not ctx.attack_upstream

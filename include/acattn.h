@@ -126,7 +126,8 @@ typedef struct acattn_bwd_io {
                            caller then reduces in a single pass */
   const uint32_t* active_qblocks; /* optional hint [B]: bit q set = some query row in [16q, 16q+16) of that sequence
                            has a non-zero cotangent (d_ctx_*); blocks with a clear bit are skipped and their dq, dqa,
-                           gate partials written as zeros.  Ignored when d_attack_mask is given.  NULL = all active.
+                           gate partials written as zeros.  With d_attack_mask given no block is skipped, but one with a
+                           clear bit only owes the soft-max of the mask scores (dqa, dka).  NULL = all active.
                            A hint, not a mask: a kernel may ignore it (the skipped work multiplies zeros anyway). */
   int32_t attack_only;  /* non-zero: the caller will read ONLY dqa and dka (pass 2 of the two-pass trainer through a
                            layer with no attack transform upstream, recbole/trainer/trainer.py:678-684); every other

@@ -321,6 +321,53 @@ def test_one_row_backward_equals_general_backward(causal, p_drop, case):
         assert (fast[n] - ref[n]).abs().max().item() <= 5e-4 * scale + 1e-6, (n, (fast[n] - ref[n]).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("p_drop", [0.0, 0.5])
+@pytest.mark.parametrize("case", [(64, 50, 64, 2), (512, 50, 64, 2), (9, 37, 64, 4), (7, 64, 128, 2)],
+                         ids=lambda c: "B%d_L%d_H%d_h%d" % c)
+def test_mask_only_blocks_equal_general_backward(causal, p_drop, case, backward_kernel):
+    """The attacked-loss pass through the last layer: the attacked context is read at one position per sequence, the
+    mask penalty's cotangent reaches every row.  Query blocks without the read position take the mask-only path of the
+    row-resident kernel; reference: the general backward with the same draws and the same cotangents, no hint."""
+    B, L, H, nh = case
+    backward_kernel(2)
+    g = torch.Generator().manual_seed(44)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    base = {k: mk(B, L, H) for k in ("q", "k", "v", "qa", "ka")}
+    base["gl"] = mk(B, L, L)
+    dh = H // nh
+    for k, shp in (("w_order", (1, 2 * dh)), ("b_order", (1,)), ("w_dist", (1, 2 * dh)), ("b_dist", (1,)), ("scalar", (1,))):
+        base[k] = (0.3 * torch.randn(*shp, generator=g)).to(DEV)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    kv = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(DEV)
+    rows = (lens - 1).view(-1, 1).to(DEV)
+    mask = A.StructuredMask(kv, causal=causal)
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
+    cot_a = torch.zeros(B, L, H, device=DEV)
+    cot_a.scatter_(1, rows.unsqueeze(-1).expand(-1, -1, H), mk(B, 1, H))
+    cot_m = 0.01 * mk(B, nh, L, L)
+    seed = 909
+
+    def grads(rnd, read_rows):
+        t = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        out = A.calibrated_attention(t["q"], t["k"], t["v"], t["qa"], t["ka"], t["gl"], mask, cfg, p_drop=p_drop,
+                                     seed=None if rnd is not None else seed, rnd=rnd, read_rows=read_rows,
+                                     w_order=t["w_order"], b_order=t["b_order"], w_dist=t["w_dist"], b_dist=t["b_dist"],
+                                     scalar=t["scalar"])
+        names = list(t)
+        return dict(zip(names, torch.autograd.grad((out[0] * cot_a).sum() + (out[2] * cot_m).sum(), [t[n] for n in names])))
+
+    fast = grads(None, rows)
+    rnd = A.materialize_randomness(B, nh, L, seed, p_drop, DEV)
+    if p_drop == 0.0:
+        rnd = A.ExplicitRandomness(noise=rnd.noise)
+    ref = grads(rnd, None)
+    for n in ref:
+        scale = ref[n].abs().max().item()
+        assert (fast[n] - ref[n]).abs().max().item() <= 5e-4 * scale + 1e-6, (n, (fast[n] - ref[n]).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("name", ["model_eval", "model_train"])
 def test_reference_schedule_switch_gives_the_same_gradients(name):
     """model.step_state.prune_dead_work = False (every tail on all positions, every layer's attacked branch, every
