@@ -1,5 +1,7 @@
 // Dispatch of acattn_calibrated_attention_bwd: streaming kernels, the row-resident kernel, then the general kernel
 // (acattn_bwd_general.inc, one translation unit per head size: acattn_bwd_dh16.hip ... acattn_bwd_dh128.hip).
+#include <stdlib.h>
+
 #include "acattn_common.h"
 
 int acattn_launch_bwd_general_dh16(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
@@ -9,7 +11,7 @@ int acattn_launch_bwd_general_dh128(const acattn_problem& p, const acattn_bwd_io
 
 int acattn_launch_bwd_fast(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
 int acattn_launch_bwd_stream(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
-int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
+int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream);
 
 namespace {
 int g_bwd_kernel = ACATTN_BWD_AUTO;
@@ -30,9 +32,28 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
   //   L > 64, or ACATTN_BWD_STREAM: the streaming two-kernel backward (acattn_bwd_stream.hip; needs io.workspace):
   //     L = 200 (H = 128, 4 heads) 0.87 ms against 7.0 ms of the general kernel.
   const int which = g_bwd_kernel;
-  if (which == ACATTN_BWD_AUTO) {  // one position per sequence carries a cotangent: one row of the backward (any L)
-    const int rc_one = acattn_launch_bwd_onerow(p, io, stream);
+  if (which == ACATTN_BWD_AUTO) {  // one position per sequence carries a context cotangent: one row of the backward (any L)
+    const int rc_one = acattn_launch_bwd_onerow(p, io, false, stream);
     if (rc_one != -100) return rc_one;
+    // ... and the attack mask a cotangent in every row (the attacked-loss pass through the last layer).  The backward is
+    // linear in its cotangents: the mask cotangent alone (no context cotangent anywhere: every query block takes the
+    // mask-only path of the row-resident kernel, which then owes dqa and dka only) + the read row's chain added on top.
+    static const bool split = getenv("ACATTN_ONEROW_SPLIT") ? atoi(getenv("ACATTN_ONEROW_SPLIT")) != 0 : true;
+    if (split && io.d_attack_mask && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.attack_only && p.L <= 64) {
+      acattn_bwd_io mask_io = io;
+      mask_io.d_ctx_attacked = mask_io.d_ctx_calibrated = nullptr;
+      mask_io.n_read_rows = 0;   // no block holds a read position
+      mask_io.attack_only = 1;   // dqa, dka alone: everything else is written by the one-row launch
+      const int rc_mask = acattn_launch_bwd_fast(p, mask_io, stream);
+      if (rc_mask == 0) {
+        acattn_bwd_io row_io = io;
+        row_io.d_attack_mask = nullptr;
+        const int rc_row = acattn_launch_bwd_onerow(p, row_io, true, stream);
+        if (rc_row != -100) return rc_row;
+        return -1;  // the mask launch ran: the read row's chain must not be dropped silently
+      }
+      if (rc_mask != -100) return rc_mask;
+    }
   }
   const bool short_rows = p.L <= 64;
   if (which == ACATTN_BWD_AUTO && short_rows) {

@@ -705,7 +705,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int DH>
+// ACC: dqa (all rows) and dka already hold the contribution of the mask cotangent (the mask-only path of the
+// row-resident kernel, which is linear in d M and independent of the context cotangents): the read row's chain is
+// added to them instead of overwriting.
+template <int DH, bool ACC>
 __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_problem P, const acattn_bwd_io IO) {
   constexpr int D4 = DH / 4;
   __shared__ __attribute__((aligned(16))) float vec[8][DH];  // q, qa, d_ctx_att, d_ctx_cal, wko, wkd, w_order_q, w_dist_q
@@ -822,7 +825,10 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
         const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
         const f4 wo_hi = *(const f4*)(P.w_order + DH + 4 * d4), wd_hi = *(const f4*)(P.w_dist + DH + 4 * d4);
         *(f4*)(IO.dk + o + 4 * d4) = q4 * dS[r] + wo_hi * d_o[r] + wd_hi * d_d[r];
-        *(f4*)(IO.dka + o + 4 * d4) = qa4 * dSa[r];
+        if (ACC)
+          *(f4*)(IO.dka + o + 4 * d4) += qa4 * dSa[r];
+        else
+          *(f4*)(IO.dka + o + 4 * d4) = qa4 * dSa[r];
         *(f4*)(IO.dv + o + 4 * d4) = ga4 * T.Ap[r] + gc4 * T.Aw[r];
       }
     }
@@ -854,8 +860,9 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
     for (int row = 0; row < L; ++row) {
       const size_t o = (rowbase + row) * H + hoff + d;
       IO.dq[o] = row == i ? sq + da_o * vec[6][d] + da_d * vec[7][d] : 0.f;
-      IO.dqa[o] = row == i ? sqa : 0.f;
+      if (!ACC) IO.dqa[o] = row == i ? sqa : 0.f;
     }
+    if (ACC) IO.dqa[(rowbase + i) * H + hoff + d] += sqa;
     IO.dw_order_part[bh * stride_w + d] = da_o * vec[0][d];
     IO.dw_dist_part[bh * stride_w + d] = da_d * vec[0][d];
     IO.dw_order_part[bh * stride_w + DH + d] = so;
@@ -872,8 +879,11 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
 
 // Returns -100 when the one-row form does not apply.
 template <int DH>
-int launch_onerow(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
-  hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH>), dim3(p.B * p.n_heads), dim3(64), 0, stream, p, io);
+int launch_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream) {
+  if (accumulate)
+    hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, true>), dim3(p.B * p.n_heads), dim3(64), 0, stream, p, io);
+  else
+    hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, false>), dim3(p.B * p.n_heads), dim3(64), 0, stream, p, io);
   return (int)hipGetLastError();
 }
 
@@ -903,7 +913,8 @@ int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p) { return (int64_t)p.
 
 // The calibrated-loss pass through the LAST layer: only the read position of every sequence carries a cotangent
 // (io.read_rows with one position per sequence, no mask cotangent).  Returns -100 when that is not the situation.
-int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
+// `accumulate`: see the kernel (the caller has run the mask path; io.d_attack_mask must then be NULL here).
+int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream) {
   static const bool enabled = getenv("ACATTN_ONEROW") ? atoi(getenv("ACATTN_ONEROW")) != 0 : true;
   const bool ok = enabled && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.d_attack_mask && !io.attack_only &&
                   p.L <= 208 && (int64_t)p.B * p.n_heads * p.L * p.L < (1LL << 30) && (int64_t)p.B * p.L * p.H < (1LL << 30) &&
@@ -911,9 +922,9 @@ int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, h
                   p.adversarial && p.combine_option == ACATTN_COMBINE_GATE && p.two_level;
   if (!ok) return -100;
   switch (p.H / p.n_heads) {
-    case 16: return launch_onerow<16>(p, io, stream);
-    case 32: return launch_onerow<32>(p, io, stream);
-    case 64: return launch_onerow<64>(p, io, stream);
+    case 16: return launch_onerow<16>(p, io, accumulate, stream);
+    case 32: return launch_onerow<32>(p, io, accumulate, stream);
+    case 64: return launch_onerow<64>(p, io, accumulate, stream);
   }
   return -100;
 }

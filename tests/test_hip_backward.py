@@ -325,12 +325,15 @@ def test_one_row_backward_equals_general_backward(causal, p_drop, case):
 @pytest.mark.parametrize("p_drop", [0.0, 0.5])
 @pytest.mark.parametrize("case", [(64, 50, 64, 2), (512, 50, 64, 2), (9, 37, 64, 4), (7, 64, 128, 2)],
                          ids=lambda c: "B%d_L%d_H%d_h%d" % c)
-def test_mask_only_blocks_equal_general_backward(causal, p_drop, case, backward_kernel):
+@pytest.mark.parametrize("which", [2, 0], ids=["row_resident", "auto_split"])
+def test_mask_only_blocks_equal_general_backward(causal, p_drop, case, which, backward_kernel):
     """The attacked-loss pass through the last layer: the attacked context is read at one position per sequence, the
     mask penalty's cotangent reaches every row.  Query blocks without the read position take the mask-only path of the
-    row-resident kernel; reference: the general backward with the same draws and the same cotangents, no hint."""
+    row-resident kernel; reference: the general backward with the same draws and the same cotangents, no hint.
+    `auto_split`: the automatic choice runs the mask cotangent through the mask-only path for EVERY block and adds the
+    read row's chain with the one-row kernel (the backward is linear in its cotangents)."""
     B, L, H, nh = case
-    backward_kernel(2)
+    backward_kernel(which)
     g = torch.Generator().manual_seed(44)
     mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
     base = {k: mk(B, L, H) for k in ("q", "k", "v", "qa", "ka")}
