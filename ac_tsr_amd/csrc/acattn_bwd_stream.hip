@@ -708,7 +708,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ACC: dqa (all rows) and dka already hold the contribution of the mask cotangent (the mask-only path of the
 // row-resident kernel, which is linear in d M and independent of the context cotangents): the read row's chain is
 // added to them instead of overwriting.
-template <int DH, bool ACC>
+template <int DH, bool ACC, bool SLICED>
 __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_problem P, const acattn_bwd_io IO) {
   constexpr int D4 = DH / 4;
   __shared__ __attribute__((aligned(16))) float vec[8][DH];  // q, qa, d_ctx_att, d_ctx_cal, wko, wkd, w_order_q, w_dist_q
@@ -764,13 +764,23 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
   const bool order_select = !causal || dead;
 
   // ---- the lane's 4 keys: S, Sa, dA_p, dA_w and the key halves of the affines as dot products ---------------------------
-  const int t = lane >> 2, g = lane & 3, j0 = 4 * lane;
+  // L <= 64: 16 key groups x 4 slices of the head dimension (lane = 16 * slice + group: the four lanes of a group each
+  // read a quarter of every row and meet in a 4-lane sum; all of them then carry the group's values, the slice-0 lanes
+  // alone feed the wave sums).  Longer rows: one key group per lane, the whole head dimension.
+  constexpr bool sliced = SLICED;  // L <= 64
+  constexpr int N4 = SLICED ? D4 / 4 : D4;            // float4 columns of a row this lane works on
+  const int kgrp = sliced ? (lane & 15) : lane;       // key group: keys 4 kgrp .. 4 kgrp + 3
+  const int slice = sliced ? (lane >> 4) : 0;
+  const int d_lo = slice * N4;
+  const float lead = slice == 0 ? 1.0f : 0.0f;
+  const int t = kgrp >> 2, g = kgrp & 3, j0 = 4 * kgrp;
   f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS, aP = aS, aW = aS, co4 = aS, cd4 = aS;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const size_t o = (rowbase + min(j0 + r, L - 1)) * H + hoff;
-#pragma unroll 2
-    for (int d4 = 0; d4 < D4; ++d4) {
+#pragma unroll
+    for (int k4 = 0; k4 < N4; ++k4) {  // (compile-time trip count: every load of the lane is in flight at once)
+      const int d4 = d_lo + k4;
       const f4 kv = *(const f4*)(P.k + o + 4 * d4), kav = *(const f4*)(P.ka + o + 4 * d4), vv = *(const f4*)(P.v + o + 4 * d4);
       const f4 q4 = *(const f4*)(&vec[0][4 * d4]), qa4 = *(const f4*)(&vec[1][4 * d4]);
       const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
@@ -783,6 +793,17 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
       cd4[r] += hsum(kv * wd4);
     }
   }
+  if (sliced) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      aS[r] = quad_sum(aS[r]);
+      aM[r] = quad_sum(aM[r]);
+      aP[r] = quad_sum(aP[r]);
+      aW[r] = quad_sum(aW[r]);
+      co4[r] = quad_sum(co4[r]);
+      cd4[r] = quad_sum(cd4[r]);
+    }
+  }
   const f4 gl = load_seg(P.gate_logits + (rowbase + i) * L, j0, L, true);
   uint32_t eb4, ab4;
   tile_bits(F, t, g, i, L, causal, true, dead, eb4, ab4);
@@ -791,10 +812,10 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
   tile_elementwise(R, K, aS, aM, aP, aW, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
 
   // ---- row scalars of the chained soft-max backward (section 4.2 of DESIGN.md, directly: the row is in registers) ----------
-  const float da = wave_sum(hsum(T.Ap * T.dAp)), dc = wave_sum(hsum(T.Aw * T.dAw));
+  const float da = wave_sum(lead * hsum(T.Ap * T.dAp)), dc = wave_sum(lead * hsum(T.Aw * T.dAw));
   const f4 dw = T.Aw * (T.dAw - dc);
   const f4 dac = (1.0f - T.gt) * dw;
-  const float r1 = wave_sum(hsum(T.Ac * dac));
+  const float r1 = wave_sum(lead * hsum(T.Ac * dac));
   const f4 du = T.Ap * (T.dAp - da), dv = T.Ac * (dac - r1);
   f4 dP = T.gt * dw + dv * T.ex1 + du * T.M;
   f4 dM = du * (T.P - T.nz) - dv * (T.P * T.ex1);
@@ -803,15 +824,17 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
     dP[r] = keep_and(dP[r] * K.keep_scale, T.ka, r);
     dM[r] = keep_and(dM[r] * K.keep_scale, T.km, r);
   }
-  const float sP = wave_sum(hsum(T.Pt * dP)), sM = wave_sum(hsum(T.Mt * dM));
+  const float sP = wave_sum(lead * hsum(T.Pt * dP)), sM = wave_sum(lead * hsum(T.Mt * dM));
   f4 dS, dSa, dgl, d_o, d_d;
   float dsc;
   tile_backward(T, K, da, dc, r1, sP, sM, f4{0.f, 0.f, 0.f, 0.f}, i, j0, dS, dSa, dgl, d_o, d_d, dsc);
-  const float da_o = wave_sum(hsum(d_o)), da_d = wave_sum(hsum(d_d)), dsc_sum = wave_sum(dsc);
-  *(f4*)(&col[0][j0]) = dS;
-  *(f4*)(&col[1][j0]) = dSa;
-  *(f4*)(&col[2][j0]) = d_o;
-  *(f4*)(&col[3][j0]) = d_d;
+  const float da_o = wave_sum(lead * hsum(d_o)), da_d = wave_sum(lead * hsum(d_d)), dsc_sum = wave_sum(lead * dsc);
+  if (slice == 0) {
+    *(f4*)(&col[0][j0]) = dS;
+    *(f4*)(&col[1][j0]) = dSa;
+    *(f4*)(&col[2][j0]) = d_o;
+    *(f4*)(&col[3][j0]) = d_d;
+  }
 
   // ---- key side: dk, dka, dv of the lane's 4 keys (rank one in the row's vectors) ------------------------------------------
 #pragma unroll
@@ -819,8 +842,9 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
     const int j = j0 + r;
     if (j < L) {
       const size_t o = (rowbase + j) * H + hoff;
-#pragma unroll 2
-      for (int d4 = 0; d4 < D4; ++d4) {
+#pragma unroll
+      for (int k4 = 0; k4 < N4; ++k4) {
+        const int d4 = d_lo + k4;
         const f4 q4 = *(const f4*)(&vec[0][4 * d4]), qa4 = *(const f4*)(&vec[1][4 * d4]);
         const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
         const f4 wo_hi = *(const f4*)(P.w_order + DH + 4 * d4), wd_hi = *(const f4*)(P.w_dist + DH + 4 * d4);
@@ -840,29 +864,53 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
       if (row == i) continue;
       for (int j = lane; j < L; j += 64) gbase[(size_t)row * L + j] = 0.f;
     }
-    store_seg(gbase + (size_t)i * L, j0, L, true, dgl);
+    if (slice == 0) store_seg(gbase + (size_t)i * L, j0, L, true, dgl);
   }
   __syncthreads();  // col[] complete
 
   // ---- query side and key halves of the parameter gradients: lane d sums over the keys --------------------------------------
   const int stride_w = IO.part_stride ? IO.part_stride : 2 * DH, stride_s = IO.part_stride ? IO.part_stride : 4;
-  for (int d = lane; d < DH; d += 64) {
+  // lane = (column d, part): with DH <= 32 the 64 / DH parts of a column split the keys (and the rows to zero) among them
+  constexpr int PARTS = DH <= 32 ? 64 / DH : 1;
+  {
+    const int d = lane % DH, part = lane / DH;
     float sq = 0.f, sqa = 0.f, so = 0.f, sd = 0.f;
-    for (int j = 0; j < L; ++j) {
-      const size_t o = (rowbase + j) * H + hoff + d;
-      const float kv = P.k[o], kav = P.ka[o];
-      sq += col[0][j] * kv;
-      sqa += col[1][j] * kav;
-      so += col[2][j] * kv;
-      sd += col[3][j] * kv;
+    constexpr int UJ = 8;  // keys per trip: their 16 loads are requested before the first is used
+    for (int jb = part; jb < L; jb += PARTS * UJ) {
+      float kv[UJ], kav[UJ];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        const int j = min(jb + u * PARTS, L - 1);
+        const size_t o = (rowbase + j) * H + hoff + d;
+        kv[u] = P.k[o];
+        kav[u] = P.ka[o];
+      }
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        const int j = jb + u * PARTS;
+        const float w = j < L ? 1.0f : 0.0f;
+        const int jc = min(j, L - 1);
+        sq += w * col[0][jc] * kv[u];
+        sqa += w * col[1][jc] * kav[u];
+        so += w * col[2][jc] * kv[u];
+        sd += w * col[3][jc] * kv[u];
+      }
+    }
+#pragma unroll
+    for (int off = DH; off < 64; off <<= 1) {
+      sq += __shfl_xor(sq, off);
+      sqa += __shfl_xor(sqa, off);
+      so += __shfl_xor(so, off);
+      sd += __shfl_xor(sd, off);
     }
     // every row of dq / dqa but the read one is zero
-    for (int row = 0; row < L; ++row) {
+    for (int row = part; row < L; row += PARTS) {
       const size_t o = (rowbase + row) * H + hoff + d;
       IO.dq[o] = row == i ? sq + da_o * vec[6][d] + da_d * vec[7][d] : 0.f;
       if (!ACC) IO.dqa[o] = row == i ? sqa : 0.f;
     }
-    if (ACC) IO.dqa[(rowbase + i) * H + hoff + d] += sqa;
+    if (ACC && part == 0) IO.dqa[(rowbase + i) * H + hoff + d] += sqa;
+    if (part != 0) return;
     IO.dw_order_part[bh * stride_w + d] = da_o * vec[0][d];
     IO.dw_dist_part[bh * stride_w + d] = da_d * vec[0][d];
     IO.dw_order_part[bh * stride_w + DH + d] = so;
@@ -880,10 +928,17 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
 // Returns -100 when the one-row form does not apply.
 template <int DH>
 int launch_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream) {
-  if (accumulate)
-    hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, true>), dim3(p.B * p.n_heads), dim3(64), 0, stream, p, io);
-  else
-    hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, false>), dim3(p.B * p.n_heads), dim3(64), 0, stream, p, io);
+  const dim3 grid(p.B * p.n_heads), block(64);
+  if (p.L <= 64) {
+    if (accumulate)
+      hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, true, true>), grid, block, 0, stream, p, io);
+    else
+      hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, false, true>), grid, block, 0, stream, p, io);
+  } else if (accumulate) {
+    hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, true, false>), grid, block, 0, stream, p, io);
+  } else {
+    hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, false, false>), grid, block, 0, stream, p, io);
+  }
   return (int)hipGetLastError();
 }
 
