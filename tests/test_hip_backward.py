@@ -452,3 +452,37 @@ def test_two_trainers_in_one_process_are_independent():
     with pytest.raises(AttributeError):  # the default state of stand-alone modules is read-only
         state.DEFAULT.pass_mode = "attack"
 
+
+
+@pytest.mark.parametrize("B,L", [(64, 50), (24, 130)])
+def test_model_gradients_do_not_depend_on_the_backward_kernels(B, L, backward_kernel):
+    """The two-pass gradients of the whole model (training mode, in-kernel randomness, pruned schedule) with the
+    automatic kernel choice -- one-row backward for the last layer's calibrated pass, mask-only blocks and the
+    mask + one-row split in the attacked pass, row-resident kernel elsewhere (L <= 64) -- against the same step with the
+    streaming row / key kernels pinned, which share none of that code.  Same torch seed, hence the same kernel seeds."""
+    cfgd = dict(n_layers=2, n_heads=2, hidden_size=64, inner_size=256, hidden_dropout_prob=0.5, attn_dropout_prob=0.5,
+                hidden_act='gelu', layer_norm_eps=1e-12, initializer_range=0.02, loss_type='CE', combine_option='gate',
+                two_level=True, use_order=True, use_distance=True, mask_loss_weight=0.03, MAX_ITEM_LIST_LENGTH=L,
+                gate_seq_length=L)
+    g = torch.Generator().manual_seed(5)
+    N = 700
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.randint(1, N, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    batch = {"item_id_list": ids.to(DEV), "item_length": lens.to(DEV), "item_id": ids[torch.arange(B), lens - 1].to(DEV)}
+
+    def grads(which):
+        backward_kernel(which)
+        torch.manual_seed(11)
+        model = A.ACSASRec(A.DictConfig(cfgd), A.ItemCount(N)).to(DEV).train()
+        trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), model)
+        torch.manual_seed(12)
+        att = trainer._pass_one(batch)[0]
+        trainer._pass_two(att)
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    auto, stream = grads(0), grads(1)
+    assert set(auto) == set(stream) and any("attack_query_transform" in n for n in auto)
+    for n in auto:
+        scale = stream[n].abs().max().item()
+        assert (auto[n] - stream[n]).abs().max().item() <= 1e-3 * scale + 1e-7, (n, (auto[n] - stream[n]).abs().max().item(), scale)
