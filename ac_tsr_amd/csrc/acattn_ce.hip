@@ -242,19 +242,33 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
 #pragma unroll
       for (int e = 0; e < 4; ++e) hf[4 * s4 + e] = v[e];
     }
+    // The LDS reads of an operand group are issued TWO groups ahead of the MFMAs that use them, into their own
+    // registers: with one wave per SIMD nothing else hides the LDS latency, and left to itself the compiler reuses one
+    // register set for consecutive groups, i.e. read -> wait -> 4 MFMAs -> read ... (a third of this loop was waiting).
     f4 dl[C::TILES];
-#pragma unroll
-    for (int t = 0; t < C::TILES; ++t) {
+    {
+      constexpr int S4 = C::KS / 4, NG = C::TILES * S4;  // operand groups: 4 k-steps of one item tile
+      auto e_group = [&](int k) -> f4 { return *(const f4*)(Es + (16 * (k / S4) + c) * C::ES + C::KS * g + 4 * (k % S4)); };
+      f4 eb[3];
+      eb[0] = e_group(0);
+      eb[1] = e_group(NG > 1 ? 1 : 0);
       f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;  // two interleaved chains (see the forward)
 #pragma unroll
-      for (int s4 = 0; s4 < C::KS / 4; ++s4) {
-        const f4 e4 = *(const f4*)(Es + (16 * t + c) * C::ES + C::KS * g + 4 * s4);
+      for (int k = 0; k < NG; ++k) {
+        if (k + 2 < NG) eb[(k + 2) % 3] = e_group(k + 2);
+        __builtin_amdgcn_sched_barrier(0);  // the read stays above this group's MFMAs (the scheduler would sink it to its use)
+        const f4 e4 = eb[k % 3];
+        const int s4 = k % S4;
         a0 = mfma16(e4[0], hf[4 * s4 + 0], a0);
         a1 = mfma16(e4[1], hf[4 * s4 + 1], a1);
         a0 = mfma16(e4[2], hf[4 * s4 + 2], a0);
         a1 = mfma16(e4[3], hf[4 * s4 + 3], a1);
+        if (s4 == S4 - 1) {
+          dl[k / S4] = a0 + a1;
+          a0 = f4{0.f, 0.f, 0.f, 0.f};
+          a1 = a0;
+        }
       }
-      dl[t] = a0 + a1;
     }
     float m_w = ACATTN_NEG_INF, s_w = 0.f;  // DIR: this wave's maximum and sum-exp for batch row c
     if (DIR) {
@@ -290,14 +304,24 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
     f4 dh[C::DT];
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) dh[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int NR = C::TILES * 4;  // item rows of this lane group, one k-step each; E^T values two rows ahead
+      float et[3][C::DT];
+      auto e_row = [&](int k, float (&dst)[C::DT]) {
+        const float* ep = Es + (16 * (k >> 2) + 4 * g + (k & 3)) * C::ES + c;
 #pragma unroll
-    for (int t = 0; t < C::TILES; ++t)
+        for (int dt = 0; dt < C::DT; ++dt) dst[dt] = ep[16 * dt];
+      };
+      e_row(0, et[0]);
+      e_row(1, et[1]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* ep = Es + (16 * t + 4 * g + r) * C::ES + c;
+      for (int k = 0; k < NR; ++k) {
+        if (k + 2 < NR) e_row(k + 2, et[(k + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt) dh[dt] = mfma16(ep[16 * dt], dl[t][r], dh[dt]);
+        for (int dt = 0; dt < C::DT; ++dt) dh[dt] = mfma16(et[k % 3][dt], dl[k >> 2][k & 3], dh[dt]);
       }
+    }
     if (WITH_TABLE_GRAD) {
       // d E (this wave's items) += dl^T . out : transpose dl through the wave's exchange area
 #pragma unroll
@@ -308,15 +332,20 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) bv[s][dt] = Hs[(4 * s + g) * C::ES + 16 * dt + c];
+      float at[2][4];  // transposed dl of an item tile, read one tile ahead
+#pragma unroll
+      for (int s = 0; s < 4; ++s) at[0][s] = Xw[(4 * s + g) * TS + c];
 #pragma unroll
       for (int t = 0; t < C::TILES; ++t) {
-        float a[4];
+        if (t + 1 < C::TILES) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = Xw[(4 * s + g) * TS + 16 * t + c];
+          for (int s = 0; s < 4; ++s) at[(t + 1) & 1][s] = Xw[(4 * s + g) * TS + 16 * (t + 1) + c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int dt = 0; dt < C::DT; ++dt) dE[t][dt] = mfma16(a[s], bv[s][dt], dE[t][dt]);
+          for (int dt = 0; dt < C::DT; ++dt) dE[t][dt] = mfma16(at[t & 1][s], bv[s][dt], dE[t][dt]);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
