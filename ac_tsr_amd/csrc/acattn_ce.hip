@@ -14,6 +14,8 @@
 // workgroup in the backward, each folded by a second tiny kernel.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "acattn_common.h"
 
 namespace {
@@ -527,6 +529,15 @@ int pick_tiles(int N) {
   return need <= 1 ? 1 : need <= 2 ? 2 : 3;
 }
 
+// forward only (no LDS, <= 256 registers): two workgroups fit a CU, so fewer tiles per wave than one round would need
+// put two waves on a SIMD and one wave's soft-max arithmetic runs under the other's MFMAs
+template <int CH>
+int pick_tiles_fwd(int N) {
+  static const int forced = getenv("ACATTN_CE_TILES_FWD") ? atoi(getenv("ACATTN_CE_TILES_FWD")) : 0;  // measurements
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 7) return forced;
+  return pick_tiles<CH>(N);
+}
+
 template <int CH, int NTILES>
 int launch_fwd_t(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
   using C = CeCfg<CH, NTILES>;
@@ -604,7 +615,11 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
   if (CH <= 64 && tiles == 3) tiles = 4;
   if (tiles > max_tiles<CH>()) tiles = max_tiles<CH>();
   const int64_t n_wg = (p.N + CE_NW * 16 * tiles - 1) / (CE_NW * 16 * tiles);
-  const int64_t fwd = n_wg * CE_NW * p.B * (int64_t)sizeof(float2);
+  int ftiles = pick_tiles_fwd<CH>(p.N);
+  if (CH <= 64 && ftiles == 3) ftiles = 4;
+  if (ftiles > max_tiles<CH>()) ftiles = max_tiles<CH>();
+  const int64_t n_wg_fwd = (p.N + CE_NW * 16 * ftiles - 1) / (CE_NW * 16 * ftiles);
+  const int64_t fwd = n_wg_fwd * CE_NW * p.B * (int64_t)sizeof(float2);
   // backward: one [B, CH] slab of d_out per workgroup (skipped, in favour of atomics, beyond kSlabLimit)
   const int64_t bwd = n_wg * p.B * CH * (int64_t)sizeof(float);
   // forward-with-direction: the same slabs plus one (max, sum-exp) pair per (workgroup, row)
@@ -614,7 +629,7 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
 
 template <int CH>
 int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
-  switch (pick_tiles<CH>(p.N)) {
+  switch (pick_tiles_fwd<CH>(p.N)) {
     case 1: return launch_fwd_t<CH, 1>(p, ws, lse, row_loss, stream);
     case 2: return launch_fwd_t<CH, 2>(p, ws, lse, row_loss, stream);
     case 3: return launch_fwd_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, stream);

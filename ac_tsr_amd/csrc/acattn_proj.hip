@@ -17,10 +17,19 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "acattn_common.h"
 
 namespace {
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
 
 template <int NB>
 struct Rows {
@@ -52,24 +61,25 @@ __device__ __forceinline__ void load_weight(const float* w, int H, int n_out, in
   }
 }
 
-// A fragments of in_grad^T = W^T . out_grad^T: lane (c, g) holds W[16t + 4g + r][16nt + c], r = 0..3 (dword gathers)
+// A fragments of in_grad^T = W^T . out_grad^T for a square [H, H] weight: lane (c, g) holds W[16t + 4g + r][16nt + c],
+// r = 0..3 (dword gathers, unconditional: a range check per element becomes a branch per load)
 template <int DT>
-__device__ __forceinline__ void load_weight_t(const float* w, int H, int n_out, int c, int g, f4 (&frag)[DT][DT]) {
-#pragma unroll
-  for (int nt = 0; nt < DT; ++nt)
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 16 * t + 4 * g + r;
-        frag[nt][t][r] = o < n_out ? w[(size_t)o * H + 16 * nt + c] : 0.f;
-      }
-}
-
-template <int DT, int NB>
-__device__ __forceinline__ void product(const f4 (&w)[DT][DT], const f4 (&in)[NB][DT], f4 (&acc)[NB][DT]) {
+__device__ __forceinline__ void load_weight_t(const float* w, int c, int g, f4 (&frag)[DT][DT]) {
+  constexpr int H = 16 * DT;
+  // contraction group t = DT - 1 is requested last: the product that starts with it has waited for the whole set
 #pragma unroll
   for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) frag[nt][t][r] = w[(16 * t + 4 * g + r) * H + 16 * nt + c];
+}
+
+// contraction groups [T0, T1) of the product (all of it by default)
+template <int DT, int NB, int T0 = 0, int T1 = DT>
+__device__ __forceinline__ void product(const f4 (&w)[DT][DT], const f4 (&in)[NB][DT], f4 (&acc)[NB][DT]) {
+#pragma unroll
+  for (int t = T0; t < T1; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -109,45 +119,73 @@ __device__ __forceinline__ void load_rows(const float* in, const Rows<NB>& W, in
     for (int t = 0; t < DT; ++t) v[nb][t] = *(const f4*)(in + (size_t)W.row[nb] * H + 16 * t + 4 * g);
 }
 
+// bias of a full-width product in accumulator layout: lane (c, g) holds b[16nt + 4g .. +3]
+template <int DT>
+__device__ __forceinline__ void load_bias(const float* bias, int g, f4 (&b)[DT]) {
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt) b[nt] = *(const f4*)(bias + 16 * nt + 4 * g);
+}
+
+template <int DT, int NB>
+__device__ __forceinline__ void set_rows(const f4 (&b)[DT], f4 (&acc)[NB][DT]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt) acc[nb][nt] = b[nt];
+}
+
+// Requests stay where they are written: without the fence the scheduler sinks every weight load to its first use and
+// the wave sits in s_waitcnt vmcnt(0) in front of each product (measured: 32 % of the wave's cycles).
+#define PIN_ORDER() __builtin_amdgcn_sched_barrier(0)
+
 template <int H, int NB>
 __global__ void __launch_bounds__(64) proj_fwd_kernel(const acattn_proj_problem P, const acattn_proj_out O) {
   constexpr int DT = H / 16;
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
   const Rows<NB> W = wave_rows<NB>(P.rows);
   f4 xb[NB][DT];
-  load_rows<DT, NB>(P.x, W, g, xb);
-  f4 wa[DT][DT], wb[DT][DT];  // the current product's fragments / the next one's
+  f4 wa[DT][DT], wb[DT][DT];  // two fragment sets: a product's weights are requested two products ahead
+  f4 ba[DT], bb[DT];          // ... and its bias with them
   f4 m[NB][DT], acc[NB][DT];
 
+  load_rows<DT, NB>(P.x, W, g, xb);
   load_weight<DT>(P.wq, H, H, c, g, wa);
+  load_bias<DT>(P.bq, g, ba);
+  PIN_ORDER();
   load_weight<DT>(P.waq, H, H, c, g, wb);
-  init_bias<DT, NB>(P.bq, H, g, m);
+  load_bias<DT>(P.baq, g, bb);
+  PIN_ORDER();
+  set_rows<DT, NB>(ba, m);
   product<DT, NB>(wa, xb, m);  // mq
   store_rows<DT, NB>(O.mq, W, g, m);
-  init_bias<DT, NB>(P.baq, H, g, acc);
+  load_weight<DT>(P.wk, H, H, c, g, wa);
+  load_bias<DT>(P.bk, g, ba);
+  PIN_ORDER();
+  set_rows<DT, NB>(bb, acc);
   product<DT, NB>(wb, m, acc);  // qa = attack_query_transform(mq)
   store_rows<DT, NB>(O.qa, W, g, acc);
-  load_weight<DT>(P.wk, H, H, c, g, wb);
   if (P.wg) {
-    // gate logits [rows, G], G = seq_length (50 ... 200): one 16-wide output tile at a time, the next tile's weight
-    // rows requested before this tile's MFMAs
+    // gate logits [rows, G], G = seq_length (50 ... 200): one 16-wide output tile at a time, weight rows requested
+    // two tiles ahead
     const int GT = (P.G + 15) >> 4;
-    f4 gw[DT], gwn[DT];
-    f4 gb, gbn;
+    f4 gw[3][DT], gb[3];
     auto load_tile = [&](int nt, f4 (&w)[DT], f4& b) {
+      nt = min(nt, GT - 1);
       const int o = min(16 * nt + c, P.G - 1);
 #pragma unroll
       for (int t = 0; t < DT; ++t) w[t] = *(const f4*)(P.wg + (size_t)o * H + 16 * t + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) b[r] = P.bg[min(16 * nt + 4 * g + r, P.G - 1)];
     };
-    load_tile(0, gw, gb);
-    for (int nt = 0; nt < GT; ++nt) {
-      load_tile(nt + 1 < GT ? nt + 1 : nt, gwn, gbn);
+    // tile nt from buffer `cur`, tile nt + 2 requested into the buffer tile nt - 1 has left (the three buffers change
+    // roles from step to step: a register copy would have to wait for the load it copies)
+    auto gate_step = [&](int nt, const f4 (&cw)[DT], const f4& cb, f4 (&fw)[DT], f4& fb) {
+      load_tile(nt + 2, fw, fb);
+      PIN_ORDER();
       f4 ga[NB][2];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        ga[nb][0] = gb;
+        ga[nb][0] = cb;
         ga[nb][1] = f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
@@ -155,42 +193,67 @@ __global__ void __launch_bounds__(64) proj_fwd_kernel(const acattn_proj_problem 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) ga[nb][r & 1] = mfma16(gw[t][r], m[nb][t][r], ga[nb][r & 1]);
+          for (int nb = 0; nb < NB; ++nb) ga[nb][r & 1] = mfma16(cw[t][r], m[nb][t][r], ga[nb][r & 1]);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const f4 v = ga[nb][0] + ga[nb][1];
-        if (W.ok[nb])
+        // the lane's four logits are consecutive in the row: one (dword-aligned) 16-byte store, not four scattered ones
+        const int j0 = 16 * nt + 4 * g;
+        float* dst = O.gate + (size_t)W.row[nb] * P.G + j0;
+        if (W.ok[nb] && j0 + 3 < P.G) {
+          *(f4u*)dst = v;
+        } else if (W.ok[nb]) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * nt + 4 * g + r;
-            if (j < P.G) O.gate[(size_t)W.row[nb] * P.G + j] = v[r];
-          }
+          for (int r = 0; r < 4; ++r)
+            if (j0 + r < P.G) dst[r] = v[r];
+        }
       }
-#pragma unroll
-      for (int t = 0; t < DT; ++t) gw[t] = gwn[t];
-      gb = gbn;
-    }
+      PIN_ORDER();
+    };
+    load_tile(0, gw[0], gb[0]);
+    load_tile(1, gw[1], gb[1]);
+    // straight-line code for the 16 possible tiles (G <= 256): around a back edge the wait-count insertion drains every
+    // request at the loop header
+    static_for<16>([&](auto k) {
+      constexpr int K = decltype(k)::value;
+      if (K < GT) gate_step(K, gw[K % 3], gb[K % 3], gw[(K + 2) % 3], gb[(K + 2) % 3]);
+    });
   }
-  load_weight<DT>(P.wak, H, H, c, g, wa);
-  init_bias<DT, NB>(P.bk, H, g, m);
-  product<DT, NB>(wb, xb, m);  // mk
+  load_weight<DT>(P.wak, H, H, c, g, wb);
+  load_bias<DT>(P.bak, g, bb);
+  PIN_ORDER();
+  set_rows<DT, NB>(ba, m);
+  product<DT, NB>(wa, xb, m);  // mk
   store_rows<DT, NB>(O.mk, W, g, m);
-  load_weight<DT>(P.wv, H, H, c, g, wb);
-  init_bias<DT, NB>(P.bak, H, g, acc);
-  product<DT, NB>(wa, m, acc);  // ka = attack_key_transform(mk)
+  load_weight<DT>(P.wv, H, H, c, g, wa);
+  load_bias<DT>(P.bv, g, ba);
+  PIN_ORDER();
+  set_rows<DT, NB>(bb, acc);
+  product<DT, NB>(wb, m, acc);  // ka = attack_key_transform(mk)
   store_rows<DT, NB>(O.ka, W, g, acc);
-  init_bias<DT, NB>(P.bv, H, g, acc);
-  product<DT, NB>(wb, xb, acc);  // mv
+  set_rows<DT, NB>(ba, acc);
+  product<DT, NB>(wa, xb, acc);  // mv
   store_rows<DT, NB>(O.mv, W, g, acc);
 }
 
-template <int H, int NB>
+// MODE fixes which cotangents exist at compile time (a run-time test around a request makes the wait-count insertion
+// assume the shorter path and drain every load in flight): 1 = all of them (the calibrated-loss walk), 2 = dqa and dka
+// only (the attacked-loss walk: everything but the attack transforms is frozen), 0 = whatever IO says.
+template <int H, int NB, int MODE>
 __global__ void __launch_bounds__(64) proj_bwd_kernel(const acattn_proj_problem P, const acattn_proj_bwd_io IO) {
   constexpr int DT = H / 16;
+  const bool h_dmq = MODE == 1 || (MODE == 0 && IO.dmq), h_dmk = MODE == 1 || (MODE == 0 && IO.dmk);
+  const bool h_dmv = MODE == 1 || (MODE == 0 && IO.dmv);
+  const bool h_dqa = MODE != 0 || IO.dqa, h_dka = MODE != 0 || IO.dka, h_dx = MODE != 0 || IO.dx;
+  const bool h_qt = MODE != 0 || IO.dmq_total, h_kt = MODE != 0 || IO.dmk_total;
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
   const Rows<NB> W = wave_rows<NB>(P.rows);
+  // Two fragment sets.  A product's transposed weights are 64 dword gathers and s_waitcnt counts at most 63 requests,
+  // so the next product's requests go out AFTER the current product's first MFMAs (whose wait then has nothing newer
+  // behind it) and have the rest of that product to arrive.
+  // Order of the products: Waq^T (A), gate tiles, Wq^T (B), Wak^T (A), Wk^T (B), Wv^T (A).
   f4 wa[DT][DT], wb[DT][DT];
-  f4 in[NB][DT], dq[NB][DT], dx[NB][DT];
+  f4 in[NB][DT], dq[NB][DT], dk[NB][DT], dx[NB][DT];
   auto zero = [&](f4 (&v)[NB][DT]) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -198,68 +261,86 @@ __global__ void __launch_bounds__(64) proj_bwd_kernel(const acattn_proj_problem 
       for (int t = 0; t < DT; ++t) v[nb][t] = f4{0.f, 0.f, 0.f, 0.f};
   };
   zero(dx);
+  const bool gate = MODE != 2 && IO.dgate && P.wg;
+  const int GT = gate ? (P.G + 15) >> 4 : 0;
+  f4 gw[2][DT];   // gate tile: A[k = 16nt + c][j = 16 kt + 4g + r] = Wg[j][k]
+  f4 gd[2][NB];   //            B[j][row] = dgate[row][j]
+  auto load_tile = [&](int kt, f4 (&w)[DT], f4 (&d)[NB]) {
+    kt = min(kt, GT - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * kt + 4 * g + r;
+      const float live = j < P.G ? 1.f : 0.f;  // the clamped element is loaded and multiplied away
+      const int jc = min(j, P.G - 1);
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) w[nt][r] = P.wg[(size_t)jc * H + 16 * nt + c] * live;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) d[nb][r] = IO.dgate[(size_t)W.row[nb] * P.G + jc];
+    }
+  };
 
   // ---- d mq (total) = dmq + dqa . Waq + dgate . Wg;  dx += d mq . Wq ------------------------------------------------
-  if (IO.dmq) load_rows<DT, NB>(IO.dmq, W, g, dq); else zero(dq);
-  if (IO.dqa) {
-    load_weight_t<DT>(P.waq, H, H, c, g, wa);
+  if (h_dmq) load_rows<DT, NB>(IO.dmq, W, g, dq); else zero(dq);
+  if (h_dqa) {
     load_rows<DT, NB>(IO.dqa, W, g, in);
-    product<DT, NB>(wa, in, dq);
+    load_weight_t<DT>(P.waq, c, g, wa);
   }
-  if (IO.dgate && P.wg) {
-    // d mq += dgate . Wg: the contraction runs over the G gate outputs, 16 at a time
-    const int GT = (P.G + 15) >> 4;
-    f4 gw[DT], gwn[DT];   // A[k = 16nt + c][j = 16 kt + 4g + r] = Wg[j][k]
-    f4 gd[NB], gdn[NB];   // B[j][row]
-    auto load_tile = [&](int kt, f4 (&w)[DT], f4 (&d)[NB]) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * kt + 4 * g + r;
-        const bool in_range = j < P.G;
-        const int jc = in_range ? j : P.G - 1;
-#pragma unroll
-        for (int nt = 0; nt < DT; ++nt) w[nt][r] = in_range ? P.wg[(size_t)jc * H + 16 * nt + c] : 0.f;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) d[nb][r] = in_range ? IO.dgate[(size_t)W.row[nb] * P.G + jc] : 0.f;
-      }
-    };
-    load_tile(0, gw, gd);
-    for (int kt = 0; kt < GT; ++kt) {
-      load_tile(kt + 1 < GT ? kt + 1 : kt, gwn, gdn);
+  PIN_ORDER();
+  if (h_dqa) product<DT, NB, DT - 1, DT>(wa, in, dq);
+  PIN_ORDER();
+  if (h_dx) load_weight_t<DT>(P.wq, c, g, wb);
+  if (gate) load_tile(0, gw[0], gd[0]);
+  PIN_ORDER();
+  if (h_dqa) product<DT, NB, 0, DT - 1>(wa, in, dq);
+  if (gate) {
+    // d mq += dgate . Wg: the contraction runs over the G gate outputs, 16 at a time, the next tile requested ahead
+    auto gate_step = [&](int kt, const f4 (&cw)[DT], const f4 (&cd)[NB], f4 (&fw)[DT], f4 (&fd)[NB]) {
+      load_tile(kt + 1, fw, fd);
+      PIN_ORDER();
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int nt = 0; nt < DT; ++nt)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) dq[nb][nt] = mfma16(gw[nt][r], gd[nb][r], dq[nb][nt]);
-#pragma unroll
-      for (int nt = 0; nt < DT; ++nt) gw[nt] = gwn[nt];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) gd[nb] = gdn[nb];
-    }
+          for (int nb = 0; nb < NB; ++nb) dq[nb][nt] = mfma16(cw[nt][r], cd[nb][r], dq[nb][nt]);
+      PIN_ORDER();
+    };
+    static_for<16>([&](auto k) {
+      constexpr int K = decltype(k)::value;
+      if (K < GT) gate_step(K, gw[K % 2], gd[K % 2], gw[(K + 1) % 2], gd[(K + 1) % 2]);
+    });
   }
-  if (IO.dmq_total) store_rows<DT, NB>(IO.dmq_total, W, g, dq);
-  if (IO.dx) {
-    load_weight_t<DT>(P.wq, H, H, c, g, wb);
-    product<DT, NB>(wb, dq, dx);
-  }
+  if (h_qt) store_rows<DT, NB>(IO.dmq_total, W, g, dq);
+  PIN_ORDER();
+  if (h_dx) product<DT, NB, DT - 1, DT>(wb, dq, dx);
+  PIN_ORDER();
 
-  // ---- d mk (total) = dmk + dka . Wak;  dx += d mk . Wk --------------------------------------------------------------
-  if (IO.dmk) load_rows<DT, NB>(IO.dmk, W, g, dq); else zero(dq);
-  if (IO.dka) {
-    load_weight_t<DT>(P.wak, H, H, c, g, wa);
+  // ---- d mk (total) = dmk + dka . Wak;  dx += d mk . Wk + d mv . Wv ---------------------------------------------------
+  if (h_dmk) load_rows<DT, NB>(IO.dmk, W, g, dk); else zero(dk);
+  if (h_dka) {
     load_rows<DT, NB>(IO.dka, W, g, in);
-    product<DT, NB>(wa, in, dq);
+    load_weight_t<DT>(P.wak, c, g, wa);
   }
-  if (IO.dmk_total) store_rows<DT, NB>(IO.dmk_total, W, g, dq);
-  if (IO.dx) {
-    load_weight_t<DT>(P.wk, H, H, c, g, wb);
-    product<DT, NB>(wb, dq, dx);
-    if (IO.dmv) {
-      load_weight_t<DT>(P.wv, H, H, c, g, wa);
+  PIN_ORDER();
+  if (h_dx) product<DT, NB, 0, DT - 1>(wb, dq, dx);
+  PIN_ORDER();
+  if (h_dka) product<DT, NB, DT - 1, DT>(wa, in, dk);
+  PIN_ORDER();
+  if (h_dx) load_weight_t<DT>(P.wk, c, g, wb);
+  PIN_ORDER();
+  if (h_dka) product<DT, NB, 0, DT - 1>(wa, in, dk);
+  if (h_kt) store_rows<DT, NB>(IO.dmk_total, W, g, dk);
+  if (h_dx) {
+    PIN_ORDER();
+    product<DT, NB, DT - 1, DT>(wb, dk, dx);
+    PIN_ORDER();
+    if (h_dmv) {
       load_rows<DT, NB>(IO.dmv, W, g, in);
-      product<DT, NB>(wa, in, dx);
+      load_weight_t<DT>(P.wv, c, g, wa);
     }
+    PIN_ORDER();
+    product<DT, NB, 0, DT - 1>(wb, dk, dx);
+    if (h_dmv) product<DT, NB>(wa, in, dx);
     store_rows<DT, NB>(IO.dx, W, g, dx);
   }
 }
@@ -267,9 +348,9 @@ __global__ void __launch_bounds__(64) proj_bwd_kernel(const acattn_proj_problem 
 int rows_per_wave(int rows) {
   static const int forced = getenv("ACATTN_PROJ_ROWS_PER_WAVE") ? atoi(getenv("ACATTN_PROJ_ROWS_PER_WAVE")) : 0;  // measurements
   if (forced == 16 || forced == 32) return forced;
-  // 16: inside the training step (B = 512, L = 50) 1.738 against 1.759 ms per step with 32 rows per wave (twice
-  // the waves, half the chain each); L = 200: 5.27 against 5.13 ms the other way round
-  return rows >= 65536 ? 32 : 16;
+  // 32 rows per wave once that still gives most SIMDs a wave: each weight fragment then feeds two row blocks.  Inside
+  // the training step (B = 512, L = 50: 25,600 rows, 800 waves) 1.540 against 1.581 ms per step with 16 rows per wave.
+  return rows >= 16384 ? 32 : 16;
 }
 
 }  // namespace
@@ -287,9 +368,16 @@ int acattn_launch_proj_fwd(const acattn_proj_problem& p, const acattn_proj_out& 
 
 int acattn_launch_proj_bwd(const acattn_proj_problem& p, const acattn_proj_bwd_io& io, hipStream_t stream) {
   const int rpw = rows_per_wave(p.rows), blocks = (p.rows + rpw - 1) / rpw;
-  if (rpw == 32)
-    hipLaunchKernelGGL((proj_bwd_kernel<64, 2>), dim3(blocks), dim3(64), 0, stream, p, io);
-  else
-    hipLaunchKernelGGL((proj_bwd_kernel<64, 1>), dim3(blocks), dim3(64), 0, stream, p, io);
+  const bool outs = io.dx && io.dmq_total && io.dmk_total, attack = io.dqa && io.dka;
+  const bool all_in = attack && io.dmq && io.dmk && io.dmv && (io.dgate || !p.wg);
+  const bool attack_only = attack && !io.dmq && !io.dmk && !io.dmv && !io.dgate;
+  const int mode = !outs ? 0 : all_in ? 1 : attack_only ? 2 : 0;
+#define LAUNCH(NB, MODE) hipLaunchKernelGGL((proj_bwd_kernel<64, NB, MODE>), dim3(blocks), dim3(64), 0, stream, p, io)
+  if (rpw == 32) {
+    if (mode == 1) LAUNCH(2, 1); else if (mode == 2) LAUNCH(2, 2); else LAUNCH(2, 0);
+  } else {
+    if (mode == 1) LAUNCH(1, 1); else if (mode == 2) LAUNCH(1, 2); else LAUNCH(1, 0);
+  }
+#undef LAUNCH
   return (int)hipGetLastError();
 }

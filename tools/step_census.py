@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""step_census.py <kernel_trace.csv> [steps]: per-step kernel census from a rocprofv3 --kernel-trace of bench.py.
+A step is delimited by ce_fwd_kernel (one launch per step).  bench.py runs the timed (full-schedule, graph) steps and then
+the plain trainer's; the census averages the steps that have the most common kernel count, i.e. the timed ones."""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+marks = [i for i, r in enumerate(rows) if "ce_fwd_kernel" in r["Kernel_Name"]]
+spans = list(zip(marks, marks[1:]))
+mode = collections.Counter(b - a for a, b in spans).most_common(1)[0][0]
+spans = [(a, b) for a, b in spans if b - a == mode]
+steps = len(spans)
+seg = [r for a, b in spans for r in rows[a:b]]
+agg = collections.defaultdict(lambda: [0, 0])
+for r in seg:
+    n = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:72]
+    agg[n][0] += 1
+    agg[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+span = sum(int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"]) for a, b in spans) / steps / 1e3
+print(f"{steps} steps   kernels/step {sum(v[0] for v in agg.values()) / steps:.1f}   sum of durations {sum(v[1] for v in agg.values()) / steps / 1e3:.1f} us"
+      f"   wall span {span:.1f} us/step")
+for n, v in sorted(agg.items(), key=lambda x: -x[1][1]):
+    print(f"{n:74s} {v[0] / steps:5.1f} x {v[1] / v[0] / 1e3:8.1f} = {v[1] / steps / 1e3:8.1f} us")
