@@ -17,6 +17,8 @@
 // Waves of a workgroup are folded through LDS, the workgroup writes one partial.
 // Stage 2 (wgrad_reduce_kernel): sums the P partials in a fixed order (deterministic, no atomics), undoes the
 // permutation, writes dW and db.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "acattn_common.h"
@@ -56,8 +58,9 @@ __device__ __forceinline__ f4 load_rows4(const float* base, int64_t row, int64_t
   return v;
 }
 
+// (256, 2): the 64 KB of LDS allow two workgroups per CU; the register budget must too
 template <int UNROLL>
-__global__ void __launch_bounds__(256) wgrad_partial_kernel(const WgradGroup G, const int64_t M,
+__global__ void __launch_bounds__(256, 2) wgrad_partial_kernel(const WgradGroup G, const int64_t M,
                                                              float* __restrict__ ws) {
   const int it = blockIdx.z;
   const int K = G.K[it], N = G.N[it];
@@ -80,23 +83,67 @@ __global__ void __launch_bounds__(256) wgrad_partial_kernel(const WgradGroup G, 
     for (int b = 0; b < 4; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
   f4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-  // row groups of 4; wave w of workgroup p takes groups (p * 4 + w) + i * 4P
-  const int64_t stride = (int64_t)P * 4 * 4;
-  for (int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 4; m0 < M; m0 += stride * UNROLL) {
-    f4 xv[UNROLL], gv[UNROLL];
+  // row groups of 4; wave w of workgroup p takes groups (p * 4 + w) + i * 4P, UNROLL groups per batch
+  const int64_t stride = (int64_t)P * 4 * 4, batch = stride * UNROLL;
+  int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+  if ((K & 63) == 0 && (N & 63) == 0) {  // (uniform per workgroup)
+    // Every block lies inside its matrix: plain 16-byte loads, a row past the end is read as row M - 1 and its dy
+    // zeroed when consumed (a select right behind the load would wait for it).  Two batch buffers: the next batch's
+    // loads are requested before the current batch's MFMAs (pinned: the scheduler would sink them behind the MFMAs
+    // again), so a wave pays one memory latency per launch, not one per batch.
+    auto load_batch = [&](int64_t r0, f4 (&xv)[UNROLL], f4 (&gv)[UNROLL]) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {  // all loads of the iteration in flight before the first MFMA
-      const int64_t row = m0 + u * stride + g;
-      xv[u] = load_rows4(x, row, M, K, kcol, K);
-      gv[u] = load_rows4(dy, row, M, N, ncol, N);
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t row = min(r0 + u * stride + g, M - 1);
+        xv[u] = *(const f4*)(x + row * K + kcol);
+        gv[u] = *(const f4*)(dy + row * N + ncol);
+      }
+    };
+    auto mma_batch = [&](int64_t r0, const f4 (&xv)[UNROLL], const f4 (&gv)[UNROLL]) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const bool row_in = r0 + u * stride + g < M;
+        f4 gq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gq[e] = row_in ? gv[u][e] : 0.f;
+        bsum += gq;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(gq[a], xv[u][b], acc[a][b]);
+      }
+    };
+    f4 xa[UNROLL], ga[UNROLL], xb[UNROLL], gb[UNROLL];
+    load_batch(m0, xa, ga);
+    // two batches per trip, no exit in between (an exit there costs a second copy of the 64 accumulators)
+#pragma nounroll
+    for (; m0 < M; m0 += 2 * batch) {
+      load_batch(m0 + batch, xb, gb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_batch(m0, xa, ga);
+      load_batch(m0 + 2 * batch, xa, ga);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m0 + batch < M) mma_batch(m0 + batch, xb, gb);  // (wave-uniform)
     }
+  } else {
+    // a block sticks out of its matrix (the gate: N = seq_length) or rows are only dword-aligned: checked loads,
+    // one batch at a time
+    for (; m0 < M; m0 += batch) {
+      f4 xv[UNROLL], gv[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      bsum += gv[u];
+      for (int u = 0; u < UNROLL; ++u) {  // all loads of the iteration in flight before the first MFMA
+        const int64_t row = m0 + u * stride + g;
+        xv[u] = load_rows4(x, row, M, K, kcol, K);
+        gv[u] = load_rows4(dy, row, M, N, ncol, N);
+      }
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int u = 0; u < UNROLL; ++u) {
+        bsum += gv[u];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(gv[u][a], xv[u][b], acc[a][b]);
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(gv[u][a], xv[u][b], acc[a][b]);
+      }
     }
   }
 
@@ -186,7 +233,8 @@ int pick_partials(int64_t M, int blocks) {
   // Measured on MI355X at M = 25,600 (tools/gpu_wgrad.sh): stage 1 takes ~10 us whether 128 or 256 workgroups
   // share a 64 x 64 block, stage 2 grows with the number of partials it folds -> few partials, but never fewer
   // than 64 workgroups per block and never less than 64 rows per workgroup.
-  int p = std::max(64, 128 / blocks);
+  static const int forced = getenv("ACATTN_WGRAD_PARTIALS") ? atoi(getenv("ACATTN_WGRAD_PARTIALS")) : 0;  // measurements
+  int p = forced > 0 ? forced : std::max(64, 128 / blocks);
   return (int)std::min<int64_t>(p, std::max<int64_t>(1, M / 64));
 }
 
@@ -233,7 +281,7 @@ int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, co
   const int64_t groups_per_wave = ((M + 3) / 4 + (int64_t)P * 4 - 1) / ((int64_t)P * 4);
   const dim3 grid(P, blocks, n_items);
   if (groups_per_wave > 4)
-    hipLaunchKernelGGL((wgrad_partial_kernel<7>), grid, dim3(256), 0, stream, G, M, (float*)ws);
+    hipLaunchKernelGGL((wgrad_partial_kernel<5>), grid, dim3(256), 0, stream, G, M, (float*)ws);
   else if (groups_per_wave >= 4)
     hipLaunchKernelGGL((wgrad_partial_kernel<4>), grid, dim3(256), 0, stream, G, M, (float*)ws);
   else
