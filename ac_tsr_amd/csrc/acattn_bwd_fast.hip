@@ -69,7 +69,9 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   float* s_dcd = s_dco + LP;
   float* s_dwq = s_dcd + LP;       // [2*DH] query halves of dw_order, dw_dist
   float* s_small = s_dwq + 2 * DH; // [8] db_order, db_dist, dscalar
-  float* scratch = s_small + 8 + wave * 16 * SS;
+  int* s_cnt = (int*)(s_small + 8);  // [4 exchanges][4 query blocks]: key tiles the block publishes (0: nothing)
+  float* scratch_all = s_small + 8 + 16;
+  float* scratch = scratch_all + wave * 16 * SS;  // this wave's published tile set: [16 query rows][SS]
 
   // ---- query-block fragments (straight from HBM) -------------------------------------------------------
   const int qb = wave, i0 = qb * 16, i = i0 + c;
@@ -265,6 +267,73 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     }
   };
 
+  // ---- key side: dv, dk, dka = sum over query rows of tile^T . rows ---------------------------------------------------
+  // The query blocks hold the tiles, the sums run over all of them.  LDS float atomics would do it in one line and
+  // are ruinous here: ds_add_f32 retires one LANE per ~3 cycles (193 cycles per wave instruction against 4 for a write,
+  // tools/probe/lds_atomic.hip), and the 160 of them per wave were half of this kernel's time.  Instead every wave
+  // PUBLISHES its tiles in its scratch area, and after a barrier wave w, OWNER of key tile w, forms that tile's sum over
+  // the publishing blocks on the MFMA and adds it to the accumulator rows only it touches.  Under the causal mask block
+  // qb publishes qb + 1 tiles while owner w reads nT - w blocks: the two triangles add up to equal work per wave.
+  // Every wave of the workgroup walks the same exchanges (launch-uniform flags), publishing nothing where its block
+  // has nothing (no cotangent, mask-only, ...): the barriers count arrivals.
+  const bool ex_att = IO.d_ctx_attacked && full, ex_cal = IO.d_ctx_calibrated && full, ex_k = full;
+  bool tiles_in_use = false;  // an earlier exchange's tiles may still be read by their owners
+  // rows of the B operand: requested before the barriers (they depend on nobody), one trip for all blocks.  A block
+  // whose rows see a valid key publishes at most qb + 1 tiles under the causal mask, so owner `wave` skips the blocks
+  // above it (a block that sees none spreads its soft-max over every key, the later ones included).
+  auto request_rows = [&](const float* rows, float (&bv)[4][4][DT]) {
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      if (qq >= nT || (qq < wave && causal && first_valid <= 16 * qq)) continue;  // (uniform) below: never published
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int qi = min(16 * qq + 4 * s + g, L - 1);  // padding rows: their tile entries are zero
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) bv[qq][s][dt] = rows[(rowbase + qi) * H + hoff + 16 * dt + c];
+      }
+    }
+  };
+  auto own_tile = [&](int e, const float (&bv)[4][4][DT], float* acc) {
+    const int4 cn = *(const int4*)(s_cnt + 4 * e);
+    const int cnt[4] = {__builtin_amdgcn_readfirstlane(cn.x), __builtin_amdgcn_readfirstlane(cn.y),
+                        __builtin_amdgcn_readfirstlane(cn.z), __builtin_amdgcn_readfirstlane(cn.w)};
+    f4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      if (qq >= nT || (qq < wave && causal && first_valid <= 16 * qq) || cnt[qq] <= wave) continue;  // (uniform)
+      any = true;
+      const float* sc = scratch_all + qq * 16 * SS;
+      float a[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = sc[(4 * s + g) * SS + 16 * wave + c];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma16(a[s], bv[qq][s][dt], o[dt]);
+    }
+    if (any) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[(16 * wave + 4 * g + r) * VS + 16 * dt + c] += o[dt][r];  // this wave's rows only
+    }
+  };
+  // one exchange: `publish` writes the block's tiles into `scratch` and returns how many (0: nothing to write)
+  auto exchange = [&](int e, const float* rows, float* acc, auto publish) {
+    float bv[4][4][DT];
+    request_rows(rows, bv);
+    if (tiles_in_use) __syncthreads();
+    tiles_in_use = true;
+    const int n = publish();
+    if (lane == 0) s_cnt[4 * e + qb] = n;
+    __syncthreads();
+    own_tile(e, bv, acc);
+  };
+  auto nothing = [] { return 0; };
+
   // MASK_ONLY: a query block none of whose rows carries a CONTEXT cotangent while the attack mask does carry one (the
   // attacked-loss pass through the last layer: the context is read at one position per sequence, the mask penalty
   // reaches every row).  With dA_p = dA_w = 0 every term of the chain vanishes except the soft-max of the mask scores:
@@ -274,37 +343,12 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
     constexpr int NTB = decltype(ntb_c)::value;
     constexpr bool MASK_ONLY = decltype(mask_only_c)::value;
 
-    // transposes a register tile set through the wave's scratch and accumulates
-    //   acc[key][d] += sum_i tile[i][key] * rows[i][d]      (LDS float atomics; rows read from global / L2)
-    auto key_side = [&](const f4 (&tile)[NTB], const float* rows, float* acc) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto tiles_of = [&](const f4 (&tile)[NTB]) {
+      return [&] {
 #pragma unroll
-      for (int t = 0; t < NTB; ++t) *(f4*)(scratch + c * SS + 16 * t + 4 * g) = tile[t];
-      float bv[4][DT];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int qi = i0 + 4 * s + g;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) bv[s][dt] = qi < L ? rows[(rowbase + qi) * H + hoff + 16 * dt + c] : 0.f;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int t = 0; t < NTB; ++t) {
-        float a[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a[s] = scratch[(4 * s + g) * SS + 16 * t + c];
-        f4 o[DT];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o[dt] = mfma16(a[s], bv[s][dt], o[dt]);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(acc + (16 * t + 4 * g + r) * VS + 16 * dt + c, o[dt][r]);
-      }
+        for (int t = 0; t < NTB; ++t) *(f4*)(scratch + c * SS + 16 * t + 4 * g) = tile[t];
+        return NTB;
+      };
     };
     // MFMA tile:  out[t] = X_tile(t) . frag^T   with X in {K, Ka, V} staged in LDS (A operand) and a row fragment (B)
     auto score_tiles = [&](const float* Xs, const float (&frag)[KS], f4 (&out)[NTB]) {
@@ -392,7 +436,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         dPa[t] = du * m;
         dMa[t] = du * (p - nz[t]);
       }
-      if (IO.d_ctx_attacked && full) key_side(Ap, IO.d_ctx_attacked, aV);
+      if (ex_att) exchange(0, IO.d_ctx_attacked, aV, tiles_of(Ap));
     }
 
     // ---- phase 2: calibrated branch ----------------------------------------------------------------------------
@@ -451,7 +495,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       }
       if (full)
         for (int t = NTB; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, f4{0.f, 0.f, 0.f, 0.f});
-      if (IO.d_ctx_calibrated && full) key_side(Aw, IO.d_ctx_calibrated, aV);
+      if (ex_cal) exchange(1, IO.d_ctx_calibrated, aV, tiles_of(Aw));
       r1 = quad_sum(r1);
 #pragma unroll
       for (int t = 0; t < NTB; ++t) {
@@ -573,9 +617,14 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         }
       }
     }
-    if constexpr (!MASK_ONLY)
-      if (full) key_side(dPa, P.q, aK);
-    key_side(dMa, P.qa, aKa);
+    if constexpr (MASK_ONLY) {  // the exchanges this block has nothing for
+      if (ex_att) exchange(0, IO.d_ctx_attacked, aV, nothing);
+      if (ex_cal) exchange(1, IO.d_ctx_calibrated, aV, nothing);
+      if (ex_k) exchange(2, P.q, aK, nothing);
+    } else {
+      if (ex_k) exchange(2, P.q, aK, tiles_of(dPa));
+    }
+    exchange(3, P.qa, aKa, tiles_of(dMa));
   };
 
   // A query block none of whose rows carries a cotangent contributes nothing anywhere: its wave only writes the zeros
@@ -596,16 +645,23 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       case 3: body(std::integral_constant<int, 3>{}, std::false_type{}); break;
       default: body(std::integral_constant<int, 4>{}, std::false_type{}); break;
     }
-  } else if (row_ok) {
-    const f4 z = {0.f, 0.f, 0.f, 0.f};
-    const uint32_t off = ((uint32_t)rowbase + i) * H + hoff + 4 * g;
+  } else {
+    if (row_ok) {
+      const f4 z = {0.f, 0.f, 0.f, 0.f};
+      const uint32_t off = ((uint32_t)rowbase + i) * H + hoff + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      if (full) *(f4*)(IO.dq + off + 16 * dt) = z;
-      *(f4*)(IO.dqa + off + 16 * dt) = z;
+      for (int dt = 0; dt < DT; ++dt) {
+        if (full) *(f4*)(IO.dq + off + 16 * dt) = z;
+        *(f4*)(IO.dqa + off + 16 * dt) = z;
+      }
+      if (full)
+        for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, z);
     }
-    if (full)
-      for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, z);
+    // no tiles of its own, but the owner of key tile `wave` all the same
+    if (ex_att) exchange(0, IO.d_ctx_attacked, aV, nothing);
+    if (ex_cal) exchange(1, IO.d_ctx_calibrated, aV, nothing);
+    if (ex_k) exchange(2, P.q, aK, nothing);
+    exchange(3, P.qa, aKa, nothing);
   }
 
   // ---- key-side results and parameter partials ---------------------------------------------------------------------
@@ -643,7 +699,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
 template <int DH>
 int launch_fast(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
   const int nT = (p.L + 15) / 16, LP = nT * 16, SS = 16 * (nT | 1);
-  const size_t lds = (size_t)(6 * LP * (DH + 4) + 6 * LP + 2 * DH + 8 + nT * 16 * SS) * sizeof(float);
+  const size_t lds = (size_t)(6 * LP * (DH + 4) + 6 * LP + 2 * DH + 8 + 16 + nT * 16 * SS) * sizeof(float);
   auto kern = acattn_bwd_fast_kernel<DH>;
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

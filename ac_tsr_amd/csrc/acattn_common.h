@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "acattn.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -44,6 +46,22 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   // D[16x16] += A[16x4] . B[4x16]; lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
   // D register r of lane l is D[4*(l>>4) + r][l&15].  Exact fp32 (a k-ordered fmaf chain).
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Requests stay where they are written.  With one wave per SIMD nothing else covers a memory latency, so weight
+// fragments are requested one or two products ahead of their MFMAs; left alone, the scheduler sinks every such load
+// to its first use and the wave sits in s_waitcnt vmcnt(0) in front of each product.
+#define PIN_ORDER() __builtin_amdgcn_sched_barrier(0)
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): straight-line code with compile-time buffer
+// rotation (a run-time loop needs register copies that wait for the loads they copy, and the wait-count insertion
+// drains every request at a loop header)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
 }
 
 // Single-instruction transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp) without the denormal

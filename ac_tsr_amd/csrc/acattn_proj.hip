@@ -23,14 +23,6 @@
 
 namespace {
 
-template <int N, int I = 0, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<N, I + 1>(f);
-  }
-}
-
 template <int NB>
 struct Rows {
   int row[NB];
@@ -134,9 +126,6 @@ __device__ __forceinline__ void set_rows(const f4 (&b)[DT], f4 (&acc)[NB][DT]) {
     for (int nt = 0; nt < DT; ++nt) acc[nb][nt] = b[nt];
 }
 
-// Requests stay where they are written: without the fence the scheduler sinks every weight load to its first use and
-// the wave sits in s_waitcnt vmcnt(0) in front of each product (measured: 32 % of the wave's cycles).
-#define PIN_ORDER() __builtin_amdgcn_sched_barrier(0)
 
 template <int H, int NB>
 __global__ void __launch_bounds__(64) proj_fwd_kernel(const acattn_proj_problem P, const acattn_proj_out O) {

@@ -103,10 +103,11 @@ __device__ __forceinline__ Rows<NB> wave_rows(const acattn_tail_problem& P) {
   return w;
 }
 
-// y = LayerNorm(z * keep + res) in the accumulator layout (lane (c, g), tile t, register r <-> row c, feature 16t+4g+r)
+// y = LayerNorm(z * keep + res) in the accumulator layout (lane (c, g), tile t, register r <-> row c, feature 16t+4g+r);
+// gamma / beta as the lane's columns of the parameters (requested by the caller, well ahead)
 template <int DT>
-__device__ __forceinline__ void ln_forward(const f4 (&z)[DT], const f4 (&res)[DT], const f4 (&keep)[DT], const float* gamma,
-                                           const float* beta, float eps, int g, f4 (&y)[DT], float& mean, float& rstd) {
+__device__ __forceinline__ void ln_forward(const f4 (&z)[DT], const f4 (&res)[DT], const f4 (&keep)[DT], const f4 (&gamma)[DT],
+                                           const f4 (&beta)[DT], float eps, f4 (&y)[DT], float& mean, float& rstd) {
   constexpr float inv_h = 1.0f / (16 * DT);
   f4 s[DT];
   float sum = 0.f;
@@ -124,8 +125,13 @@ __device__ __forceinline__ void ln_forward(const f4 (&z)[DT], const f4 (&res)[DT
   }
   rstd = __builtin_amdgcn_rsqf(quad_sum(sq) * inv_h + eps);
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
-    y[t] = (s[t] * rstd) * *(const f4*)(gamma + 16 * t + 4 * g) + *(const f4*)(beta + 16 * t + 4 * g);
+  for (int t = 0; t < DT; ++t) y[t] = (s[t] * rstd) * gamma[t] + beta[t];
+}
+
+template <int DT>
+__device__ __forceinline__ void load_cols(const float* v, int g, f4 (&out)[DT]) {
+#pragma unroll
+  for (int t = 0; t < DT; ++t) out[t] = *(const f4*)(v + 16 * t + 4 * g);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -138,74 +144,14 @@ __device__ __forceinline__ void ln_forward(const f4 (&z)[DT], const f4 (&res)[DT
 template <int H, int I, int NB, int NW = 1>
 __global__ void __launch_bounds__(64 * NW) tail_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
   static_assert(NW == 1 || NB == 1, "the slab split works on one row block");
-  constexpr int DT = H / 16, IT = I / 16;
+  constexpr int DT = H / 16, IT = I / 16, NS = IT / NW;  // NS slabs per wave: mt = wave, wave + NW, ...
+  static_assert(NS >= 2, "two slabs are requested ahead");
   const int c = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
   const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const Rows<NB> W = wave_rows<NB>(P);
   const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
 
-  // ---- h1 = dense(ctx) + bias -----------------------------------------------------------------------------------
-  f4 cb[NB][DT];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int t = 0; t < DT; ++t) cb[nb][t] = *(const f4*)(P.ctx + (size_t)W.src[nb] * H + 16 * t + 4 * g);
-  f4 h1[NB][DT];
-#pragma unroll
-  for (int nt = 0; nt < DT; ++nt) {
-    const f4 b = *(const f4*)(P.bd + 16 * nt + 4 * g);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) h1[nb][nt] = b;
-  }
-  {
-    f4 wd[DT][DT];
-#pragma unroll
-    for (int nt = 0; nt < DT; ++nt)
-#pragma unroll
-      for (int t = 0; t < DT; ++t) wd[nt][t] = *(const f4*)(P.wd + (size_t)(16 * nt + c) * H + 16 * t + 4 * g);
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int nt = 0; nt < DT; ++nt)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) h1[nb][nt] = mfma16(wd[nt][t][r], cb[nb][t][r], h1[nb][nt]);
-  }
-
-  // ---- a = LayerNorm(dropout(h1) + x) ---------------------------------------------------------------------------
-  f4 a[NB][DT];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    f4 res[DT], keep[DT];
-#pragma unroll
-    for (int t = 0; t < DT; ++t) {
-      res[t] = *(const f4*)(P.x + (size_t)W.src[nb] * H + 16 * t + 4 * g);
-      keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, W.row[nb], 4 * t + g, H);
-    }
-    float mean, rstd;
-    ln_forward<DT>(h1[nb], res, keep, P.g1, P.b1, P.eps1, g, a[nb], mean, rstd);
-    if (W.ok[nb] && wave == 0) {
-#pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
-        *(f4*)(S.h1 + o) = h1[nb][t];
-        *(f4*)(S.a + o) = a[nb][t];
-      }
-      if (g == 0) *(float2*)(S.st1 + 2 * (size_t)W.row[nb]) = float2{mean, rstd};
-    }
-  }
-
-  // ---- h3 = dense_2(gelu(dense_1(a))), one 16-column slab of the inner dimension at a time -----------------------
-  f4 h3[NB][DT];
-#pragma unroll
-  for (int nt = 0; nt < DT; ++nt) {
-    const f4 b = wave == 0 ? *(const f4*)(P.bb2 + 16 * nt + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) h3[nb][nt] = b;
-  }
-  // weight fragments (and the bias) of a slab are requested one slab ahead: nothing the current slab's MFMAs wait for
-  // is younger than the previous iteration's requests (vmcnt retires in order)
+  // weight fragments (and the bias) of one 16-column slab of the inner dimension
   struct Slab {
     f4 w1[DT];  // A[m = 16mt+c][k = 16t+4g+r]
     f4 w2[DT];  // A[n = 16t+c][m = 16mt+4g+r]
@@ -219,12 +165,70 @@ __global__ void __launch_bounds__(64 * NW) tail_fwd_kernel(const acattn_tail_pro
     }
     s.b1 = *(const f4*)(P.bb1 + 16 * mt + 4 * g);
   };
-  Slab cur, nxt;
-  load_slab(wave, cur);
-#pragma unroll 2
-  for (int mt = wave; mt < IT; mt += NW) {
-    load_slab(mt + NW < IT ? mt + NW : mt, nxt);
-    f4 h2[NB][2];  // two partial accumulators: a dependent 16x16x4 chain issues every 40 cycles, alternating every 32
+
+  // ---- every request of the prologue at once: rows, dense weights, LayerNorm parameters, the first two slabs ---------
+  f4 cb[NB][DT], res[NB][DT];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      cb[nb][t] = *(const f4*)(P.ctx + (size_t)W.src[nb] * H + 16 * t + 4 * g);
+      res[nb][t] = *(const f4*)(P.x + (size_t)W.src[nb] * H + 16 * t + 4 * g);
+    }
+  f4 wd[DT][DT], bd[DT], g1[DT], b1[DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+    for (int t = 0; t < DT; ++t) wd[nt][t] = *(const f4*)(P.wd + (size_t)(16 * nt + c) * H + 16 * t + 4 * g);
+  load_cols<DT>(P.bd, g, bd);
+  load_cols<DT>(P.g1, g, g1);
+  load_cols<DT>(P.b1, g, b1);
+  Slab sl[3];  // the slab in use, the next one (its first product already runs), the one after that (in flight)
+  load_slab(wave, sl[0]);
+  load_slab(wave + NW, sl[1]);
+  PIN_ORDER();
+
+  // ---- h1 = dense(ctx) + bias;  a = LayerNorm(dropout(h1) + x) ---------------------------------------------------------
+  f4 h1[NB][DT], a[NB][DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) h1[nb][nt] = bd[nt];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) h1[nb][nt] = mfma16(wd[nt][t][r], cb[nb][t][r], h1[nb][nt]);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f4 keep[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, W.row[nb], 4 * t + g, H);
+    float mean, rstd;
+    ln_forward<DT>(h1[nb], res[nb], keep, g1, b1, P.eps1, a[nb], mean, rstd);
+    if (W.ok[nb] && wave == 0) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)W.row[nb] * H + 16 * t + 4 * g;
+        *(f4*)(S.h1 + o) = h1[nb][t];
+        *(f4*)(S.a + o) = a[nb][t];
+      }
+      if (g == 0) *(float2*)(S.st1 + 2 * (size_t)W.row[nb]) = float2{mean, rstd};
+    }
+  }
+
+  // ---- h3 = dense_2(gelu(dense_1(a))), one slab at a time ----------------------------------------------------------------
+  // Step j: request slab j + 2; first product of slab j + 1 (MFMA) next to the GELU of slab j (VALU: nothing else of
+  // this wave could run under those MFMAs); second product of slab j.
+  f4 h3[NB][DT], bb2[DT], g2[DT], b2[DT];
+  load_cols<DT>(P.bb2, g, bb2);
+  load_cols<DT>(P.g2, g, g2);
+  load_cols<DT>(P.b2, g, b2);
+  auto first_product = [&](const Slab& s, f4 (&h2)[NB][2]) {
+    // two partial accumulators: a dependent 16x16x4 chain issues every 40 cycles, alternating every 32
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) h2[nb][0] = h2[nb][1] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -232,10 +236,24 @@ __global__ void __launch_bounds__(64 * NW) tail_fwd_kernel(const acattn_tail_pro
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) h2[nb][r & 1] = mfma16(cur.w1[t][r], a[nb][t][r], h2[nb][r & 1]);
+        for (int nb = 0; nb < NB; ++nb) h2[nb][r & 1] = mfma16(s.w1[t][r], a[nb][t][r], h2[nb][r & 1]);
+  };
+  f4 h2[2][NB][2];
+  first_product(sl[0], h2[0]);
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) h3[nb][nt] = wave == 0 ? bb2[nt] : f4{0.f, 0.f, 0.f, 0.f};
+  static_for<NS>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    const int mt = wave + NW * J;
+    if (J + 2 < NS) load_slab(mt + 2 * NW, sl[(J + 2) % 3]);
+    PIN_ORDER();
+    const Slab& cur = sl[J % 3];
+    if (J + 1 < NS) first_product(sl[(J + 1) % 3], h2[(J + 1) & 1]);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const f4 pre = (h2[nb][0] + h2[nb][1]) + cur.b1;
+      const f4 pre = (h2[J & 1][nb][0] + h2[J & 1][nb][1]) + cur.b1;
       f4 act;
 #pragma unroll
       for (int r = 0; r < 4; ++r) act[r] = gelu_erf(pre[r]);
@@ -245,8 +263,8 @@ __global__ void __launch_bounds__(64 * NW) tail_fwd_kernel(const acattn_tail_pro
 #pragma unroll
         for (int nt = 0; nt < DT; ++nt) h3[nb][nt] = mfma16(cur.w2[nt][r], act[r], h3[nb][nt]);
     }
-    cur = nxt;
-  }
+    PIN_ORDER();
+  });
 
   if (NW > 1) {  // fold the waves' partial products into wave 0
     __shared__ f4 red[NW > 1 ? NW - 1 : 1][DT][64];
@@ -269,7 +287,7 @@ __global__ void __launch_bounds__(64 * NW) tail_fwd_kernel(const acattn_tail_pro
 #pragma unroll
     for (int t = 0; t < DT; ++t) keep[t] = row_keep_scale(P.p2, P.keep2, P.seed2 + step, W.row[nb], 4 * t + g, H);
     float mean, rstd;
-    ln_forward<DT>(h3[nb], a[nb], keep, P.g2, P.b2, P.eps2, g, y, mean, rstd);
+    ln_forward<DT>(h3[nb], a[nb], keep, g2, b2, P.eps2, y, mean, rstd);
     if (W.ok[nb]) {
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
