@@ -34,6 +34,20 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 __device__ __forceinline__ float hsum(const f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
+// Diagnostic builds only (-DACATTN_BWD_STAMPS, tools/gpu_bwd_stamps.sh): s_memtime per phase and wave, kept in scalar
+// registers and written at the end to g_bwd_stamps[wave][16].  No stamp executes in the product build.
+#ifdef ACATTN_BWD_STAMPS
+__device__ unsigned long long g_bwd_stamps[8192 * 16];
+#define BWD_STAMP(k)                                                                  \
+  do {                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_[k])::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+  } while (0)
+#else
+#define BWD_STAMP(k)
+#endif
+
 template <int DH>
 __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_problem P, const acattn_bwd_io IO) {
   constexpr int KS = DH / 4;
@@ -53,6 +67,10 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   const size_t rowbase = (size_t)b * L;
   const int hoff = h * DH;
   const size_t bh = (size_t)b * nh + h;
+#ifdef ACATTN_BWD_STAMPS
+  unsigned long long stamp_[16] = {};
+#endif
+  BWD_STAMP(0);
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;                // [LP][VS]
@@ -134,6 +152,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   const f4 w_ko = *(const f4*)(P.w_order + DH + 4 * (threadIdx.x % (DH / 4)));
   const f4 w_kd = *(const f4*)(P.w_dist + DH + 4 * (threadIdx.x % (DH / 4)));
   const uint8_t r_valid = (threadIdx.x < L) ? P.key_valid[rowbase + threadIdx.x] : (uint8_t)0;
+  BWD_STAMP(1);
 #pragma unroll
   for (int it = 0; it < KV_IT; ++it) {
     const int idx = threadIdx.x + it * blockDim.x;
@@ -185,6 +204,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   const uint64_t seed_eff = P.seed + (P.seed_device ? *P.seed_device : 0ull);
   const RngKey rkey = rng_key(seed_eff);
   __syncthreads();
+  BWD_STAMP(2);
 
   const unsigned long long valid_keys = __ballot(lane < L && s_km[lane] == 0.f);
   const int first_valid = valid_keys ? __ffsll((long long)valid_keys) - 1 : L;
@@ -389,6 +409,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       for (int r = 0; r < 4; ++r) tM[t][r] = ex2(y[r] - lse_y2) * okf;
     }
 
+    BWD_STAMP(3);
     // ---- phase 1: perturbed branch ---------------------------------------------------------------------------
     f4 dPa[NTB], dMa[NTB];
     uint32_t keepA = 0, keepM = 0;  // dropout keep bits, 4 per tile
@@ -439,6 +460,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       if (ex_att) exchange(0, IO.d_ctx_attacked, aV, tiles_of(Ap));
     }
 
+    BWD_STAMP(4);
     // ---- phase 2: calibrated branch ----------------------------------------------------------------------------
     if constexpr (!MASK_ONLY) {
       f4 dAw[NTB], Ac[NTB], Aw[NTB];
@@ -516,6 +538,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       }
     }
 
+    BWD_STAMP(5);
     // ---- phase 3: through the first-level softmaxes; spatial-calibrator gradients ------------------------------
     float r2 = 0.f, r3 = 0.f;
 #pragma unroll
@@ -585,6 +608,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       }
     }
 
+    BWD_STAMP(6);
     // ---- phase 4: dq, dqa; dk, dka ------------------------------------------------------------------------------
     {
       f4 oq[DT], oqa[DT];
@@ -617,6 +641,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         }
       }
     }
+    BWD_STAMP(7);
     if constexpr (MASK_ONLY) {  // the exchanges this block has nothing for
       if (ex_att) exchange(0, IO.d_ctx_attacked, aV, nothing);
       if (ex_cal) exchange(1, IO.d_ctx_calibrated, aV, nothing);
@@ -625,6 +650,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       if (ex_k) exchange(2, P.q, aK, tiles_of(dPa));
     }
     exchange(3, P.qa, aKa, tiles_of(dMa));
+    BWD_STAMP(8);
   };
 
   // A query block none of whose rows carries a cotangent contributes nothing anywhere: its wave only writes the zeros
@@ -666,6 +692,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
 
   // ---- key-side results and parameter partials ---------------------------------------------------------------------
   __syncthreads();
+  BWD_STAMP(9);
   for (int idx = threadIdx.x; idx < L * (DH / 4); idx += blockDim.x) {
     const int row = idx / (DH / 4), c4 = idx - row * (DH / 4);
     const f4 r1k = s_dco[row] * *(const f4*)(P.w_order + DH + 4 * c4) + s_dcd[row] * *(const f4*)(P.w_dist + DH + 4 * c4);
@@ -694,6 +721,13 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   }
   if (threadIdx.x < 4)
     IO.dsmall_part[bh * (IO.part_stride ? IO.part_stride : 4) + threadIdx.x] = threadIdx.x < 3 ? s_small[threadIdx.x] : 0.f;
+#ifdef ACATTN_BWD_STAMPS
+  BWD_STAMP(10);
+  if (lane == 0 && blockIdx.x * 4 + wave < 8192) {
+    stamp_[11] = (unsigned long long)qb;
+    for (int k = 0; k < 12; ++k) g_bwd_stamps[(blockIdx.x * 4 + wave) * 16 + k] = stamp_[k];
+  }
+#endif
 }
 
 template <int DH>
@@ -724,3 +758,9 @@ int acattn_launch_bwd_fast(const acattn_problem& p, const acattn_bwd_io& io, hip
   }
   return -100;
 }
+
+#ifdef ACATTN_BWD_STAMPS
+extern "C" int acattn_debug_bwd_stamps(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_stamps), (size_t)n_words * 8);
+}
+#endif
