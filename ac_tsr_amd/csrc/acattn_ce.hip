@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_fwd_kernel(const acattn_ce_prob
     }
   }
   const int nrb = (B + 15) >> 4;
+  const bool ragged = item0 + C::ITEMS > N;  // (uniform per wave)
   float hf[C::KS];
   auto load_rows = [&](int rb, float (&dst)[C::KS]) {
     const int row = 16 * rb + c;
@@ -85,21 +86,32 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_fwd_kernel(const acattn_ce_prob
     for (int s = 0; s < C::KS; ++s)
 #pragma unroll
       for (int t = 0; t < C::TILES; ++t) acc[t] = mfma16(ef[t][s], hf[s], acc[t]);
-    float m = ACATTN_NEG_INF;
-#pragma unroll
-    for (int t = 0; t < C::TILES; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (item0 + 16 * t + 4 * g + r >= N) acc[t][r] = ACATTN_NEG_INF;
-        m = fmaxf(m, acc[t][r]);
-      }
-    m = quad_max(m);
-    float sum = 0.f;
-    if (m > ACATTN_NEG_INF) {
+    // The fp32 MFMAs do not run beside VALU work on this chip (tools/probe/coexec.hip), so every instruction between two
+    // row blocks' products counts: the catalogue-end test only in the one wave that straddles the end (uniform), the
+    // exponent as one fused multiply-add on register pairs (v_pk_fma_f32), the sum on pairs as well.
+    if (ragged) {
 #pragma unroll
       for (int t = 0; t < C::TILES; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sum += __builtin_amdgcn_exp2f((acc[t][r] - m) * kLog2e);
+        for (int r = 0; r < 4; ++r)
+          if (item0 + 16 * t + 4 * g + r >= N) acc[t][r] = ACATTN_NEG_INF;
+    }
+    float m = ACATTN_NEG_INF;
+#pragma unroll
+    for (int t = 0; t < C::TILES; ++t) m = fmaxf(fmaxf(fmaxf(fmaxf(m, acc[t][0]), acc[t][1]), acc[t][2]), acc[t][3]);  // 2 x v_max3
+    m = quad_max(m);
+    float sum = 0.f;
+    if (m > ACATTN_NEG_INF) {
+      const float m2 = m * kLog2e;
+      f4 sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < C::TILES; ++t) {
+        f4 x = acc[t] * kLog2e - m2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+        sv += x;
+      }
+      sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
     }
     sum = quad_sum(sum);
     const int row = 16 * rb + c;
