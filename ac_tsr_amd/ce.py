@@ -42,6 +42,7 @@ class _FullSortCE(torch.autograd.Function):
         _lib.check(lib.acattn_full_sort_ce_fwd(C.byref(p), _ptr(ws), _ptr(lse), _ptr(row_loss), _stream()), "full_sort_ce_fwd")
         ctx.save_for_backward(out, table, target, lse)
         ctx.ws_bytes = nbytes
+        ctx.tick = state.next_tick()
         return row_loss
 
     @staticmethod
@@ -57,6 +58,7 @@ class _FullSortCE(torch.autograd.Function):
         d_table = torch.empty_like(table) if want_table else None
         _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(coef), _ptr(ws), _ptr(d_out), _ptr(d_table),
                                                _stream()), "full_sort_ce_bwd")
+        ctx.state.publish_table_grad(getattr(ctx, "tick", -1), table, d_table)  # (see StepState.table_grad)
         return d_out, d_table, None, None
 
 
@@ -89,6 +91,7 @@ class _FullSortCEDir(torch.autograd.Function):
             _lib.check(rc, "full_sort_ce_fwd_dir")
         ctx.has_dir = direction is not None
         ctx.save_for_backward(out, table, target, lse, direction if direction is not None else lse)
+        ctx.tick = state.next_tick()
         ctx.ws_bytes = nbytes
         return row_loss
 
@@ -105,6 +108,7 @@ class _FullSortCEDir(torch.autograd.Function):
         d_table = torch.empty_like(table) if want_table else None
         _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_row_loss.contiguous()), _ptr(ws), _ptr(d_out),
                                                _ptr(d_table), _stream()), "full_sort_ce_bwd")
+        ctx.state.publish_table_grad(getattr(ctx, "tick", -1), table, d_table)  # (see StepState.table_grad)
         return d_out, d_table, None, None
 
 
@@ -130,6 +134,7 @@ class _FullSortCEMean(torch.autograd.Function):
         d_table = torch.empty_like(table) if want_table else None
         _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_loss.contiguous()), _ptr(ws), _ptr(d_out),
                                                _ptr(d_table), _stream()), "full_sort_ce_bwd")
+        ctx.state.publish_table_grad(getattr(ctx, "tick", -1), table, d_table)  # (see StepState.table_grad)
         return d_out, d_table, None, None
 
 

@@ -56,6 +56,7 @@ class _EmbedLayerNorm(torch.autograd.Function):
         ctx.save_for_backward(idx, table, pos if pos is not None else empty, gamma, beta, stats,
                               keep if keep is not None else empty, seed_tensor if seed_tensor is not None else empty)
         ctx.args = (eps, p_drop, pos is not None, keep is not None, seed, seed_tensor is not None, padding_idx)
+        ctx.tick = state.next_tick()
         ctx.mark_non_differentiable(nonzero)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" of the validity bytes (one launch per backward)
         return y, nonzero
@@ -70,7 +71,10 @@ class _EmbedLayerNorm(torch.autograd.Function):
         p = _problem(idx, table, pos if has_pos else None, gamma, beta, eps, p_drop, keep if has_keep else None, seed,
                      seed_tensor if has_seed_t else None)
         L, H, chunks = p.L, p.H, _lib.EMBED_BWD_CHUNKS
-        d_table = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
+        # the loss node's dense table gradient, if one was published in this walk: the rows are scattered into it and
+        # the table gets no second gradient from here (no zero fill, no [N, H] add); else a zero-filled buffer of our own
+        handed = ctx.state.take_table_grad(ctx.tick, table) if ctx.needs_input_grad[1] else None
+        d_table = handed if handed is not None else (torch.zeros_like(table) if ctx.needs_input_grad[1] else None)
         want_pos = has_pos and ctx.needs_input_grad[2]
         pos_part = torch.empty(chunks, L, H, device=table.device, dtype=torch.float32) if want_pos else None
         want_gb = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
@@ -86,7 +90,7 @@ class _EmbedLayerNorm(torch.autograd.Function):
         if want_gb:
             gb = ops.sum_rows(gb_part, 0)
             dgamma, dbeta = gb[0], gb[1]
-        return None, d_table, d_pos, dgamma, dbeta, None, None, None, None, None, None, None
+        return None, (None if handed is not None else d_table), d_pos, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def embed_layer_norm(item_seq: torch.Tensor, item_embedding: torch.nn.Embedding,

@@ -18,7 +18,7 @@ import torch
 
 
 class StepState:
-    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "_frozen")
+    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "_frozen")
 
     def __init__(self, frozen: bool = False):
         object.__setattr__(self, "_frozen", False)
@@ -30,6 +30,13 @@ class StepState:
         # XORed into every kernel seed drawn for this model: data-parallel ranks seed torch's CPU generator alike, the
         # salt (set from the rank by the trainer) keeps row b of every shard from drawing the same noise and dropout
         self.seed_salt: int = 0
+        # The item table receives two gradients in one backward walk: the full-sort cross-entropy's dense [N, H] one and
+        # the embedding lookup's scattered rows.  Left to autograd they meet in a 25.6 MB add (plus the zero fill of the
+        # scatter target).  Instead the cross-entropy node PUBLISHES its gradient tensor here and the embedding node,
+        # which autograd runs later (it is upstream), scatters straight into it and returns nothing for the table.
+        # `tick` orders forwards: the embedding node only takes a gradient published by a loss node built after it.
+        self.tick: int = 0
+        self.table_grad = None  # (tick of the publishing node's forward, the table, its gradient tensor)
         object.__setattr__(self, "_frozen", frozen)
 
     def __setattr__(self, name, value):
@@ -70,6 +77,27 @@ class StepState:
     def attack_pass(self):
         """Inside: only layers tagged `_acattn_attack = True` produce parameter gradients."""
         return self._pass("attack")
+
+    def next_tick(self) -> int:
+        """Forward-order stamp of an autograd node (-1 on the frozen default: no hand-over there)."""
+        if self._frozen:
+            return -1
+        self.tick += 1
+        return self.tick
+
+    def publish_table_grad(self, tick: int, table: torch.Tensor, grad: Optional[torch.Tensor]) -> None:
+        if not self._frozen and tick >= 0 and grad is not None:
+            self.table_grad = (tick, table, grad)
+
+    def take_table_grad(self, tick: int, table: torch.Tensor) -> Optional[torch.Tensor]:
+        """The gradient tensor a loss node downstream of the caller published for `table` in this backward walk."""
+        if self._frozen or self.table_grad is None or tick < 0:
+            return None
+        t, tab, grad = self.table_grad
+        if t > tick and tab.data_ptr() == table.data_ptr() and grad.shape == table.shape:
+            self.table_grad = None
+            return grad
+        return None
 
     def draw_seed(self) -> int:
         """One 63-bit seed for the library's counter RNG from torch's CPU generator (reproducible under

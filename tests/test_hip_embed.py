@@ -80,3 +80,44 @@ def test_counter_dropout_statistics_eval_identity_and_bad_ids():
     assert torch.isfinite(out).all()
     with pytest.raises(IndexError):
         fused_embed.embed_layer_norm(torch.ones(2, L + 4, dtype=torch.long, device=DEV), emb, pos, norm, 0.0, False)
+
+
+def test_table_gradient_hand_over_equals_autograd_sum():
+    """The item table is both the embedding table and the CE classifier (acsasrec.py:87, 117-120).  With a StepState the
+    cross-entropy node publishes its dense table gradient and the embedding backward scatters into it
+    (StepState.table_grad); without one autograd adds the two.  Same gradients either way, also over two walks, and
+    nothing is handed over to a lookup of another table or across walks."""
+    from ac_tsr_amd import ce
+    from ac_tsr_amd.state import StepState
+    B, L, H, N = 16, 12, 64, 300
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randint(0, N, (B, L), generator=g).to(DEV)
+    target = torch.randint(1, N, (B,), generator=g).to(DEV)
+    cot = torch.randn(B, L, H, generator=g).to(DEV)
+
+    def grads(state):
+        torch.manual_seed(0)
+        emb = torch.nn.Embedding(N, H, padding_idx=0).to(DEV)
+        pos = torch.nn.Embedding(L, H).to(DEV)
+        norm = torch.nn.LayerNorm(H, eps=1e-12).to(DEV)
+        if state is not None:
+            for m in (emb, pos, norm):
+                state.attach(m)
+        out = []
+        for _ in range(2):  # two forward/backward walks: nothing stale survives the first
+            emb.weight.grad = None
+            y = fused_embed.embed_layer_norm(idx, emb, pos, norm, 0.0, training=True)
+            loss = ce.full_sort_cross_entropy(y[:, -1, :], emb.weight, target, **({} if state is None else {"state": state}))
+            (loss + (y * cot).sum() * 1e-2).backward()
+            out.append(emb.weight.grad.clone())
+        return out
+
+    st = StepState()
+    ref, got = grads(None), grads(st)
+    assert st.tick == 4 and st.table_grad is None  # published twice, taken twice
+    for a, b in zip(ref, got):
+        assert (a - b).abs().max() <= 1e-6 * a.abs().max() + 1e-9
+    # a gradient published for ANOTHER table is left alone
+    other = torch.nn.Embedding(N, H, padding_idx=0).to(DEV)
+    st.publish_table_grad(10 ** 9, other.weight, torch.zeros_like(other.weight))
+    assert grads(st)[0].sub(ref[0]).abs().max() <= 1e-6 * ref[0].abs().max() + 1e-9
