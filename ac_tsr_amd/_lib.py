@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -84,7 +84,7 @@ class ProjOut(C.Structure):
 
 class ProjBwdIO(C.Structure):
     _fields_ = [("dmq", _f), ("dmk", _f), ("dmv", _f), ("dqa", _f), ("dka", _f), ("dgate", _f), ("dmq_total", _f),
-                ("dmk_total", _f), ("dx", _f)]
+                ("dmk_total", _f), ("dx", _f), ("dx_init", _f)]
 
 
 class TailProblem(C.Structure):

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(64) proj_bwd_kernel(const acattn_proj_problem 
 #pragma unroll
       for (int t = 0; t < DT; ++t) v[nb][t] = f4{0.f, 0.f, 0.f, 0.f};
   };
-  zero(dx);
+  if (IO.dx_init && h_dx) load_rows<DT, NB>(IO.dx_init, W, g, dx); else zero(dx);  // the residual path's share of dx
   const bool gate = MODE != 2 && IO.dgate && P.wg;
   const int GT = gate ? (P.G + 15) >> 4 : 0;
   f4 gw[2][DT];   // gate tile: A[k = 16nt + c][j = 16 kt + 4g + r] = Wg[j][k]

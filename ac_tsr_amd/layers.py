@@ -173,7 +173,7 @@ class AttackRTransformerLayer(nn.Module):
         is position-wise, so it then runs on the selected rows alone (the models read one position per sequence of the
         last layer, abstract_recommender.py:130-134; AcBERT4Rec the masked positions, acbert4rec.py:219-225)."""
         att = self.attack_attention
-        mq, mk, mv, qa, ka, gate_logits = projections(
+        mq, mk, mv, qa, ka, gate_logits, hidden_res = projections(
             hidden_states, att.query, att.key, att.value, att.attack_query_transform, att.attack_key_transform,
             self.gate if self.combine_option == 'gate' else None, attack_upstream=_attack_upstream)
         cfg = self._config()
@@ -188,13 +188,13 @@ class AttackRTransformerLayer(nn.Module):
             mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
             seed_tensor=state_of(self).seed_tensor if core_rnd is None else None, read_rows=_rows,
             attack_upstream=_attack_upstream, state=state_of(self), rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
-        residual = hidden_states
+        residual = hidden_res  # hidden_states, via the projection node (its backward launch takes the residual gradient)
         if _rows is not None:
             index = _rows.unsqueeze(-1).expand(-1, -1, hidden_states.shape[-1])
             pick = lambda t: None if t is None else t.gather(1, index)
             picks_itself = ctx_cal.is_cuda and tail.supported(att, self.feed_forward) and tail.fused_supported(att, self.feed_forward)
             if not picks_itself:
-                residual = pick(hidden_states)
+                residual = pick(hidden_res)
         else:
             pick = lambda t: t
 
@@ -203,7 +203,7 @@ class AttackRTransformerLayer(nn.Module):
             fused = one_launch or (ctx_layer.is_cuda and torch.is_grad_enabled() and tail.supported(att, self.feed_forward))
             if one_launch and _rows is not None:
                 # the fused tail picks the rows itself: no gather launches in front of it, no scatter launches behind
-                return tail.layer_tail(ctx_layer, hidden_states, att, self.feed_forward, pick(keep_out), pick(keep_ffn),
+                return tail.layer_tail(ctx_layer, hidden_res, att, self.feed_forward, pick(keep_out), pick(keep_ffn),
                                        pick=_rows)
             ctx_layer, keep_out, keep_ffn = pick(ctx_layer), pick(keep_out), pick(keep_ffn)
             if fused:

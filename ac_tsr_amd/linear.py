@@ -178,10 +178,13 @@ class _FusedProjections(torch.autograd.Function):
         ctx.attack_upstream = attack_upstream
         ctx.state = state
         ctx.set_materialize_grads(False)
-        return mq, mk, mv, qa, ka, gate
+        # x again, as an output of this node: the layer hands it to its tails as the residual (layers.py:683), so their
+        # d_x arrives HERE and the backward launch starts dx from it (acattn_proj_bwd_io.dx_init) instead of autograd
+        # adding the two [rows, H] gradients of x with an elementwise launch per layer and walk
+        return mq, mk, mv, qa, ka, gate, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dmq, dmk, dmv, dqa, dka, dgate):
+    def backward(ctx, dmq, dmk, dmv, dqa, dka, dgate, d_res=None):
         import ctypes as C
         from . import _lib
         from .ops import _ptr, _stream, linear_wgrad_grouped
@@ -189,16 +192,19 @@ class _FusedProjections(torch.autograd.Function):
         params = [t if t.numel() else None for t in ctx.saved_tensors[3:]]
         two = lambda t: None if t is None else t.reshape(-1, t.shape[-1])
         con = lambda t: None if t is None else t.contiguous()
-        dmq, dmk, dmv, dqa, dka, dgate = (con(t) for t in (dmq, dmk, dmv, dqa, dka, dgate))
+        dmq, dmk, dmv, dqa, dka, dgate, d_res = (con(t) for t in (dmq, dmk, dmv, dqa, dka, dgate, d_res))
         if not ctx.has_gate:
             dgate = None
         others = not ctx.state.attack_pass_only  # pass 2 keeps only the attack transforms (trainer.py:678-684)
         attack = not ctx.state.calibrated_pass_only  # pass 1 has them frozen (trainer.py:672-677)
         need_dx = ctx.needs_input_grad[0] and (others or ctx.attack_upstream)
         dx = dmq_t = dmk_t = None
-        if need_dx or others:
+        if all(t is None for t in (dmq, dmk, dmv, dqa, dka, dgate)):  # only the residual path carries a gradient
+            dx = d_res if need_dx else None
+        elif need_dx or others:
             io = _lib.ProjBwdIO()
             io.dmq, io.dmk, io.dmv, io.dqa, io.dka, io.dgate = (_ptr(t) for t in (dmq, dmk, dmv, dqa, dka, dgate))
+            io.dx_init = _ptr(d_res) if need_dx else None
             # dmq / dmk are the attention node's freshly allocated dq / dk: completing them in place touches nothing
             # anyone else reads
             dmq_t = dmq if dmq is not None else torch.empty_like(x)
@@ -228,8 +234,9 @@ class _FusedProjections(torch.autograd.Function):
 
 
 def projections(x, query, key, value, attack_query, attack_key, gate=None, attack_upstream=True):
-    """(mq, mk, mv, qa, ka, gate_logits or None) of one encoder layer; see _Projections.  `attack_upstream=False`
-    tells the node that nothing that produced `x` holds attack transforms (the first encoder layer)."""
+    """(mq, mk, mv, qa, ka, gate_logits or None, x_res) of one encoder layer; see _Projections.  `attack_upstream=False`
+    tells the node that nothing that produced `x` holds attack transforms (the first encoder layer).  `x_res` is `x`
+    for the residual connections of the layer (see _FusedProjections.forward; plain `x` on the other paths)."""
     node = _Projections if torch.is_grad_enabled() else None
     if x.is_cuda and FUSED_PROJECTIONS and x.dtype == torch.float32 and all(
             m.bias is not None for m in (query, key, value, attack_query, attack_key) + ((gate,) if gate is not None else ())):
@@ -238,11 +245,12 @@ def projections(x, query, key, value, attack_query, attack_key, gate=None, attac
             node = _FusedProjections  # the single launch serves evaluation (no_grad) as well
     if not x.is_cuda or node is None:
         mq, mk, mv = query(x), key(x), value(x)
-        return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None)
-    return node.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
-                              attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
-                              gate.weight if gate is not None else None, gate.bias if gate is not None else None,
-                              attack_upstream, state_of(query))
+        return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None), x
+    out = node.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
+                     attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
+                     gate.weight if gate is not None else None, gate.bias if gate is not None else None,
+                     attack_upstream, state_of(query))
+    return out if len(out) == 7 else (*out, x)
 
 
 class _FullSortScores(torch.autograd.Function):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 21
+#define ACATTN_ABI_VERSION 22
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -370,6 +370,9 @@ typedef struct acattn_proj_bwd_io {
   const float *dmq, *dmk, *dmv, *dqa, *dka; /* [rows,H] */
   const float* dgate;                       /* [rows,G] */
   float *dmq_total, *dmk_total, *dx;        /* [rows,H] */
+  /* [rows,H] or NULL: dx starts from it.  x also feeds the layer tails as the residual (layers.py:683): their d_x is
+   * handed in here instead of being added to dx by a separate elementwise launch. */
+  const float* dx_init;
 } acattn_proj_bwd_io;
 
 int acattn_projections_supported(int32_t H, int32_t G);

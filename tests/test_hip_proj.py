@@ -100,3 +100,21 @@ def test_fused_projections_equal_library_node():
         assert (a - b).abs().max() <= 2e-5
     for n, a, b in zip(names, res[0][1], res[1][1]):
         assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, n
+
+
+@pytest.mark.parametrize("rows", [100, 25600])
+def test_residual_gradient_enters_the_backward_launch(rows):
+    """The node's seventh output is x for the layer's residual connections: a cotangent on it is the start value of dx
+    in the backward launch (acattn_proj_bwd_io.dx_init), i.e. dx = dx(projections) + d_res, and alone it passes through."""
+    H, G = 64, 50
+    t, cot = _inputs(rows, H, G, seed=5)
+    dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
+    res_cot = torch.randn(rows, H, generator=torch.Generator().manual_seed(9)).to(DEV)
+    outs = linear._FusedProjections.apply(dev["x"], *(dev[n] for n in W), True, StepState())
+    assert len(outs) == 7 and outs[6].data_ptr() == dev["x"].data_ptr()
+    loss = sum((o * cot[k].to(DEV)).sum() for k, o in zip(OUT, outs))
+    base, = torch.autograd.grad(loss, [dev["x"]], retain_graph=True)
+    both, = torch.autograd.grad(loss + (outs[6] * res_cot).sum(), [dev["x"]], retain_graph=True)
+    assert (both - (base + res_cot)).abs().max() <= 1e-5 * (base.abs().max() + 1)
+    alone, = torch.autograd.grad((outs[6] * res_cot).sum(), [dev["x"]])
+    assert torch.equal(alone, res_cot)
