@@ -947,13 +947,15 @@ int launch_stream(const acattn_problem& p, const acattn_bwd_io& io, float* ws, h
   const int nT = (p.L + 15) / 16, dh = DH;
   const size_t rows = (size_t)p.B * p.n_heads;
   if (!io.attack_only) {  // the parameter partial rows are accumulated with atomics: start from zero
+    // (acattn_launch_zero, not hipMemsetAsync: see acattn_util.hip)
+    auto zero = [&](float* ptr, size_t n) { (void)acattn_launch_zero(ptr, n, stream); };
     if (io.part_stride) {
       float* lo = std::min(io.dw_order_part, std::min(io.dw_dist_part, io.dsmall_part));
-      if (hipError_t e = hipMemsetAsync(lo, 0, rows * io.part_stride * sizeof(float), stream); e != hipSuccess) return (int)e;
+      zero(lo, rows * io.part_stride);
     } else {
-      (void)hipMemsetAsync(io.dw_order_part, 0, rows * 2 * dh * sizeof(float), stream);
-      (void)hipMemsetAsync(io.dw_dist_part, 0, rows * 2 * dh * sizeof(float), stream);
-      (void)hipMemsetAsync(io.dsmall_part, 0, rows * 4 * sizeof(float), stream);
+      zero(io.dw_order_part, rows * 2 * dh);
+      zero(io.dw_dist_part, rows * 2 * dh);
+      zero(io.dsmall_part, rows * 4);
     }
   }
   const dim3 grid(p.B * p.n_heads * nT), block(64);

@@ -571,8 +571,7 @@ int launch_bwd_t(const acattn_ce_problem& p, const float* lse, const float* coef
   const int64_t n_out = (int64_t)p.B * CH;
   float* slab = (n_wg * n_out * (int64_t)sizeof(float) <= kSlabLimit) ? (float*)ws : nullptr;
   if (!slab) {
-    const hipError_t e = hipMemsetAsync(d_out, 0, (size_t)n_out * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
+    if (const int e = acattn_launch_zero(d_out, (size_t)n_out, stream)) return e;  // (not hipMemsetAsync: acattn_util.hip)
   }
   if (d_table) {
     auto k = ce_bwd_kernel<CH, NTILES, true>;

@@ -275,3 +275,5 @@ int acattn_launch_penalty_bwd_scaled(const float* m, const float* norm, const fl
                                      float* d_m, hipStream_t stream);
 int acattn_launch_penalty_bwd(const float* m, const float* norm, const float* d_norm, int64_t n, float* d_m,
                               hipStream_t stream);
+// zero fill by a kernel (acattn_util.hip: memset nodes inside a hipGraph proved unreliable for accumulate-into-zero buffers)
+int acattn_launch_zero(float* p, size_t n, hipStream_t stream);

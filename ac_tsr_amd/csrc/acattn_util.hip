@@ -220,3 +220,28 @@ int acattn_launch_sum_rows(const float* x, float* out, int batch, int R, int C, 
   hipLaunchKernelGGL(sum_rows_kernel<false>, grid, dim3(256), 0, stream, x, out, R, C, R, CT);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// zero fill as a KERNEL.  hipMemsetAsync nodes captured into a hipGraph did not reliably take effect before the kernels
+// that accumulate into the buffer (float atomics into parameter partial rows / d_out): stale sums grew from replay to
+// replay until the parameters went non-finite after ~70-120 steps of the L = 200, d = 128 configuration
+// (tools/nan_probe_graph.py); eager launches were never affected.  Every accumulate-into-zero site uses this instead.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) zero_fill_kernel(float* __restrict__ p, size_t n) {
+  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 + 3 < n && (reinterpret_cast<uintptr_t>(p + i0) & 15) == 0) {
+    *(f4*)(p + i0) = f4{0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i0 + e < n) p[i0 + e] = 0.f;
+  }
+}
+}  // namespace
+
+int acattn_launch_zero(float* p, size_t n, hipStream_t stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, p, n);
+  return (int)hipGetLastError();
+}

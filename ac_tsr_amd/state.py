@@ -17,6 +17,10 @@ from typing import Optional
 import torch
 
 
+import os as _os
+_NO_HANDOVER = _os.environ.get("ACATTN_NO_HANDOVER") == "1"  # measurement / bisection hook
+
+
 class StepState:
     __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "_frozen")
 
@@ -91,7 +95,7 @@ class StepState:
 
     def take_table_grad(self, tick: int, table: torch.Tensor) -> Optional[torch.Tensor]:
         """The gradient tensor a loss node downstream of the caller published for `table` in this backward walk."""
-        if self._frozen or self.table_grad is None or tick < 0:
+        if self._frozen or self.table_grad is None or tick < 0 or _NO_HANDOVER:
             return None
         t, tab, grad = self.table_grad
         if t > tick and tab.data_ptr() == table.data_ptr() and grad.shape == table.shape:
