@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -137,6 +137,7 @@ SYMBOLS = {
     "acattn_layer_tail_bwd_partial_rows": (C.c_int32, [C.c_int32]),
     "acattn_select_layer_tail_blocks": (C.c_int, [C.c_int]),
     "acattn_sum_rows": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "acattn_sum_rows_pair": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "acattn_mask_penalty_fwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_void_p]),
     "acattn_mask_penalty_partial": (C.c_int, [_f, C.c_int64, _f, C.c_void_p]),
     "acattn_attacked_loss_finish": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_int64, C.c_float, _f, _f, C.c_int32,

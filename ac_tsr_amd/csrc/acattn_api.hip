@@ -262,6 +262,15 @@ int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_
   return rc;
 }
 
+int acattn_sum_rows_pair(const float* x1, float* out1, int32_t batch1, int32_t R1, int32_t C1, const float* x2, float* out2,
+                         int32_t batch2, int32_t R2, int32_t C2, void* stream) {
+  if (!x1 || !out1 || !x2 || !out2) return fail("x and out must be non-NULL");
+  if (batch1 < 1 || R1 < 1 || C1 < 1 || batch2 < 1 || R2 < 1 || C2 < 1) return fail("batch, R, C must be positive");
+  const int rc = acattn_launch_sum_rows_pair(x1, out1, batch1, R1, C1, x2, out2, batch2, R2, C2, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 static int check_embed(const acattn_embed_problem* p) {
   if (!p) return fail("embed problem is NULL");
   if (p->rows < 1 || p->L < 1 || p->rows % p->L != 0) return fail("rows must be a positive multiple of L");

@@ -251,6 +251,8 @@ int acattn_launch_ln_fwd(const acattn_ln_problem& p, float* y, float* stats, hip
 int acattn_launch_ln_bwd(const acattn_ln_problem& p, const float* dy, const float* stats, float* dz, float* dres,
                          float* dgb_part, hipStream_t stream);
 int acattn_launch_sum_rows(const float* x, float* out, int batch, int R, int C, hipStream_t stream);
+int acattn_launch_sum_rows_pair(const float* x1, float* out1, int batch1, int R1, int C1, const float* x2, float* out2,
+                                int batch2, int R2, int C2, hipStream_t stream);
 void acattn_set_error(const char* msg);
 bool acattn_proj_supported(int H, int G);
 int acattn_launch_proj_fwd(const acattn_proj_problem& p, const acattn_proj_out& o, hipStream_t stream);

@@ -263,9 +263,19 @@ class _CalibratedAttention(torch.autograd.Function):
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
         if attack_only:
             return (None, None, None, dqa, dka) + (None,) * 17
-        if dgate_part is not None:
-            dgate = sum_rows(dgate_part, 1)  # the gate is shared by the heads (layers.py:887 unsqueeze(1))
-        tot = sum_rows(part, 0)
+        if dgate_part is not None and dgate_part.shape[1] > 1 and part.shape[0] < 4096:
+            # the gate is shared by the heads (layers.py:887 unsqueeze(1)): its per-head gradients and the parameter
+            # partials are summed by ONE launch
+            Bq, nhq, Lq = dgate_part.shape[0], dgate_part.shape[1], dgate_part.shape[2]
+            dgate = torch.empty(Bq, Lq, dgate_part.shape[3], device=part.device, dtype=torch.float32)
+            tot = torch.empty(part.shape[1], device=part.device, dtype=torch.float32)
+            _lib.check(lib.acattn_sum_rows_pair(_ptr(dgate_part), _ptr(dgate), Bq, nhq, Lq * dgate_part.shape[3],
+                                                _ptr(part), _ptr(tot), 1, part.shape[0], part.shape[1], _stream()),
+                       "sum_rows_pair")
+        else:
+            if dgate_part is not None:
+                dgate = sum_rows(dgate_part, 1)
+            tot = sum_rows(part, 0)
         small = tot[4 * dh:]
         g_wo = tot[:2 * dh].view_as(w_order) if w_order is not None else None
         g_bo = small[0:1].view_as(b_order) if w_order is not None else None

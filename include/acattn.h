@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 22
+#define ACATTN_ABI_VERSION 23
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -233,6 +233,10 @@ int acattn_embed_layernorm_bwd(const acattn_embed_problem* p, const float* dy, c
 /* out[bt, c] = sum_r x[bt, r, c]  (x is [batch, R, C] contiguous).  The reductions of the training step's backward:
  * bias gradients (sum over B*L rows), split-K slabs, per-(b,head) parameter partials, per-head gate gradients. */
 int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_t C, void* stream);
+/* Two such reductions in one launch (independent shapes): the attention backward's parameter partials and its per-head
+ * gate gradient (layers.py:887: the gate is shared by the heads) are summed together. */
+int acattn_sum_rows_pair(const float* x1, float* out1, int32_t batch1, int32_t R1, int32_t C1, const float* x2, float* out2,
+                         int32_t batch2, int32_t R2, int32_t C2, void* stream);
 
 /* The mask penalty || 1 - M ||_2 over a whole attack-mask tensor (torch.norm(1 - attack_mask, p=2):
  * recbole/model/sequential_recommender/acsasrec.py:131-137, acbert4rec.py:229-232) and its gradient
