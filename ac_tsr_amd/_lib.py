@@ -15,7 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 23
+ABI_VERSION = 24
+MAX_MASKS = 8  # ACATTN_MAX_MASKS
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
 COMBINE = {"fixed": 0, "gate": 1, "annealing": 2}
@@ -140,6 +141,9 @@ SYMBOLS = {
     "acattn_sum_rows_pair": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "acattn_mask_penalty_fwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_void_p]),
     "acattn_mask_penalty_partial": (C.c_int, [_f, C.c_int64, _f, C.c_void_p]),
+    "acattn_mask_penalty_partial_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, _f, C.c_void_p]),
+    "acattn_mask_penalty_bwd_scaled_multi": (C.c_int, [C.c_void_p, _f, _f, C.c_float, C.c_int64, C.c_void_p, C.c_int32,
+                                                       C.c_void_p]),
     "acattn_attacked_loss_finish": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_int64, C.c_float, _f, _f, C.c_int32,
                                               C.c_void_p]),
     "acattn_mask_penalty_bwd_scaled": (C.c_int, [_f, _f, _f, C.c_float, C.c_int64, _f, C.c_void_p]),

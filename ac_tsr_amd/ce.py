@@ -169,8 +169,13 @@ class _AttackedLoss(torch.autograd.Function):
             _lib.check(rc, "full_sort_ce_fwd_dir")
         masks = tuple(m.contiguous() for m in masks)
         part = torch.empty(len(masks), _lib.PENALTY_WS_FLOATS, device=out.device, dtype=torch.float32)
-        for l, m in enumerate(masks):
-            _lib.check(lib.acattn_mask_penalty_partial(_ptr(m), m.numel(), _ptr(part[l]), _stream()), "mask_penalty_partial")
+        if 1 < len(masks) <= _lib.MAX_MASKS:  # every mask in one launch
+            ptrs = (C.c_void_p * len(masks))(*(m.data_ptr() for m in masks))
+            _lib.check(lib.acattn_mask_penalty_partial_multi(ptrs, len(masks), masks[0].numel(), _ptr(part), _stream()),
+                       "mask_penalty_partial_multi")
+        else:
+            for l, m in enumerate(masks):
+                _lib.check(lib.acattn_mask_penalty_partial(_ptr(m), m.numel(), _ptr(part[l]), _stream()), "mask_penalty_partial")
         res = torch.empty(2 + len(masks), device=out.device, dtype=torch.float32)
         _lib.check(lib.acattn_attacked_loss_finish(_ptr(row_loss), B, _ptr(part), len(masks), masks[0].numel(), weight,
                                                    _ptr(res), _ptr(direction), 0 if direction is None else direction.numel(),
@@ -198,6 +203,14 @@ class _AttackedLoss(torch.autograd.Function):
         else:
             d_out = direction * d_loss  # direction already carries -1/B
         d_masks = []
+        if 1 < len(masks) <= _lib.MAX_MASKS and all(ctx.needs_input_grad[5 + l] for l in range(len(masks))):
+            d_masks = [torch.empty_like(m) for m in masks]  # every mask's gradient in one launch
+            mp = (C.c_void_p * len(masks))(*(m.data_ptr() for m in masks))
+            dp = (C.c_void_p * len(masks))(*(d.data_ptr() for d in d_masks))
+            _lib.check(lib.acattn_mask_penalty_bwd_scaled_multi(mp, _ptr(res[2:]), _ptr(d_loss), ctx.weight / len(masks),
+                                                                masks[0].numel(), dp, len(masks), _stream()),
+                       "mask_penalty_bwd_scaled_multi")
+            return (d_out, d_table, None, None, None, *d_masks)
         for l, m in enumerate(masks):
             if not ctx.needs_input_grad[5 + l]:
                 d_masks.append(None)

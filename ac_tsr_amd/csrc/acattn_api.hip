@@ -346,6 +346,28 @@ int acattn_mask_penalty_bwd_scaled(const float* m, const float* norm, const floa
   return rc;
 }
 
+int acattn_mask_penalty_partial_multi(const float* const* m, int32_t n_masks, int64_t n, float* part, void* stream) {
+  if (!m || !part) return fail("m and part must be non-NULL");
+  if (n < 1 || n_masks < 1 || n_masks > ACATTN_MAX_MASKS) return fail("n must be positive, 1 <= n_masks <= ACATTN_MAX_MASKS");
+  for (int l = 0; l < n_masks; ++l)
+    if (!m[l] || ((uintptr_t)m[l] & 15) != 0) return fail("every mask must be non-NULL and 16-byte aligned");
+  const int rc = acattn_launch_penalty_partial_multi(m, n_masks, n, part, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_mask_penalty_bwd_scaled_multi(const float* const* m, const float* norms, const float* d_loss, float scale, int64_t n,
+                                         float* const* d_m, int32_t n_masks, void* stream) {
+  if (!m || !norms || !d_loss || !d_m) return fail("m, norms, d_loss and d_m must be non-NULL");
+  if (n < 1 || n_masks < 1 || n_masks > ACATTN_MAX_MASKS) return fail("n must be positive, 1 <= n_masks <= ACATTN_MAX_MASKS");
+  for (int l = 0; l < n_masks; ++l)
+    if (!m[l] || !d_m[l] || (((uintptr_t)m[l] | (uintptr_t)d_m[l]) & 15) != 0)
+      return fail("every m and d_m must be non-NULL and 16-byte aligned");
+  const int rc = acattn_launch_penalty_bwd_scaled_multi(m, norms, d_loss, scale, n, d_m, n_masks, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int64_t acattn_linear_wgrad_workspace_bytes(int64_t M, int32_t K, int32_t N) {
   if (M < 1 || K < 1 || N < 1) return fail("M, K, N must be positive");
   return acattn_linear_wgrad_ws_bytes(M, K, N);

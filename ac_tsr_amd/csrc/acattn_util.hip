@@ -186,6 +186,49 @@ __global__ void __launch_bounds__(256) penalty_bwd_scaled_kernel(const float* __
   }
 }
 
+// all masks of the model in one launch each way (blockIdx.y = mask): a launch per mask sat at the ~5 us floor
+struct PenaltyMasks {
+  const float* m[ACATTN_MAX_MASKS];
+  float* d_m[ACATTN_MAX_MASKS];
+};
+__global__ void __launch_bounds__(256) penalty_partial_multi_kernel(const PenaltyMasks M, const int64_t n,
+                                                                    float* __restrict__ part) {
+  const float* __restrict__ m = M.m[blockIdx.y];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f4 d = 1.0f - *(const f4*)(m + 4 * i);
+    acc += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float d = 1.0f - m[(n4 << 2) + threadIdx.x];
+    acc += d * d;
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * kPenaltyGrid + blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(256) penalty_bwd_scaled_multi_kernel(const PenaltyMasks M, const float* __restrict__ norms,
+                                                                       const float* __restrict__ d_loss, const float scale,
+                                                                       const int64_t n) {
+  const float* __restrict__ m = M.m[blockIdx.y];
+  float* __restrict__ d_m = M.d_m[blockIdx.y];
+  const float nv = norms[blockIdx.y];
+  const float k = nv > 0.f ? d_loss[0] * scale / nv : 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    *(f4*)(d_m + 4 * i) = (*(const f4*)(m + 4 * i) - 1.0f) * k;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t j = (n4 << 2) + threadIdx.x;
+    d_m[j] = (m[j] - 1.0f) * k;
+  }
+}
+
 }  // namespace
 
 int64_t acattn_penalty_ws_floats() { return kPenaltyGrid; }
@@ -201,6 +244,22 @@ static int penalty_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<i
 
 int acattn_launch_penalty_partial(const float* m, int64_t n, float* part, hipStream_t stream) {
   hipLaunchKernelGGL(penalty_partial_kernel, dim3(penalty_grid(n)), dim3(256), 0, stream, m, n, part);
+  return (int)hipGetLastError();
+}
+
+int acattn_launch_penalty_partial_multi(const float* const* m, int n_masks, int64_t n, float* part, hipStream_t stream) {
+  PenaltyMasks M{};
+  for (int l = 0; l < n_masks; ++l) M.m[l] = m[l];
+  hipLaunchKernelGGL(penalty_partial_multi_kernel, dim3(penalty_grid(n), n_masks), dim3(256), 0, stream, M, n, part);
+  return (int)hipGetLastError();
+}
+
+int acattn_launch_penalty_bwd_scaled_multi(const float* const* m, const float* norms, const float* d_loss, float scale,
+                                           int64_t n, float* const* d_m, int n_masks, hipStream_t stream) {
+  PenaltyMasks M{};
+  for (int l = 0; l < n_masks; ++l) M.m[l] = m[l], M.d_m[l] = d_m[l];
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n / 4 + 255) / 256, 2048));
+  hipLaunchKernelGGL(penalty_bwd_scaled_multi_kernel, dim3(grid, n_masks), dim3(256), 0, stream, M, norms, d_loss, scale, n);
   return (int)hipGetLastError();
 }
 

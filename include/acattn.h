@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 23
+#define ACATTN_ABI_VERSION 24
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -259,6 +259,12 @@ int acattn_attacked_loss_finish(const float* row_loss, int32_t B, const float* p
                                 float weight, float* out, float* scale_buf, int32_t n_scale, void* stream);
 int acattn_mask_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n, float* d_m,
                                    void* stream);
+/* The same two for all masks of a model (one per layer, each of n elements, at most ACATTN_MAX_MASKS) in ONE launch each:
+ * part [n_masks, ACATTN_PENALTY_WS_FLOATS]; norms [n_masks] (the out + 2 of acattn_attacked_loss_finish). */
+#define ACATTN_MAX_MASKS 8
+int acattn_mask_penalty_partial_multi(const float* const* m, int32_t n_masks, int64_t n, float* part, void* stream);
+int acattn_mask_penalty_bwd_scaled_multi(const float* const* m, const float* norms, const float* d_loss, float scale, int64_t n,
+                                         float* const* d_m, int32_t n_masks, void* stream);
 
 /* Parameter gradients of y = x W^T + b (torch.nn.functional.linear as called for query/key/value, the attack
  * transforms, dense, the gate and the feed-forward pair: recbole/model/layers.py:687-690, 660-661, 681, 792-794, 863):
