@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, g = lane >> 4;
   const int item0 = (blockIdx.x * CE_NW + wave) * C::ITEMS;
+  const bool ragged = item0 + C::ITEMS > P.N;  // (uniform per wave)
   const int B = P.B, N = P.N;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -284,35 +285,46 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         }
       }
     }
+    // (as in the forward: the catalogue-end test only in the wave that straddles the end, the exponents' arguments and the
+    // scaling on register pairs -- these instructions do not run beside the fp32 MFMAs)
+    if (ragged) {
+#pragma unroll
+      for (int t = 0; t < C::TILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (item0 + 16 * t + 4 * g + r >= N) dl[t][r] = ACATTN_NEG_INF;  // exp2(-inf) = 0 past the catalogue end
+    }
     float m_w = ACATTN_NEG_INF, s_w = 0.f;  // DIR: this wave's maximum and sum-exp for batch row c
     if (DIR) {
 #pragma unroll
-      for (int t = 0; t < C::TILES; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (item0 + 16 * t + 4 * g + r >= N) dl[t][r] = ACATTN_NEG_INF;
-          m_w = fmaxf(m_w, dl[t][r]);
-        }
+      for (int t = 0; t < C::TILES; ++t) m_w = fmaxf(fmaxf(fmaxf(fmaxf(m_w, dl[t][0]), dl[t][1]), dl[t][2]), dl[t][3]);
       m_w = quad_max(m_w);
       const float m2 = m_w > ACATTN_NEG_INF ? m_w * kLog2e : 0.f;
+      f4 sv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < C::TILES; ++t)
+      for (int t = 0; t < C::TILES; ++t) {
+        f4 x = dl[t] * kLog2e - m2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dl[t][r] = __builtin_amdgcn_exp2f(dl[t][r] * kLog2e - m2);  // exp2(-inf) = 0 past the catalogue end
-          s_w += dl[t][r];
-        }
-      s_w = quad_sum(s_w);
+        for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+        dl[t] = x;
+        sv += x;
+      }
+      s_w = quad_sum((sv[0] + sv[1]) + (sv[2] + sv[3]));
     } else {
+      // the target's one-hot: the tile and register that hold it are found once per row block, not tested per element
+      const int t_t = tgt >> 4, g_t = (tgt >> 2) & 3, r_t = tgt & 3;  // (tgt < 0: no tile matches)
+      const bool mine = tgt >= 0 && tgt < C::ITEMS && g_t == g;
 #pragma unroll
-      for (int t = 0; t < C::TILES; ++t)
+      for (int t = 0; t < C::TILES; ++t) {
+        f4 x = dl[t] * kLog2e - l2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int it = 16 * t + 4 * g + r;
-          float p = (item0 + it < N) ? __builtin_amdgcn_exp2f(dl[t][r] * kLog2e - l2) : 0.f;
-          if (it == tgt) p -= 1.0f;
-          dl[t][r] = p * cf;
+        for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+        if (mine && t == t_t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] -= (r == r_t) ? 1.0f : 0.0f;
         }
+        dl[t] = x * cf;
+      }
     }
     // d out^T (this wave's items) = E^T . dl^T : dl registers are the B operand as they stand
     f4 dh[C::DT];
