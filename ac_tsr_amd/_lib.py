@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 MAX_MASKS = 8  # ACATTN_MAX_MASKS
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
@@ -88,6 +88,15 @@ class ProjBwdIO(C.Structure):
                 ("dmk_total", _f), ("dx", _f), ("dx_init", _f)]
 
 
+ADAM_MAX_TENSORS = 64
+
+
+class AdamGroup(C.Structure):
+    _fields_ = [("n_tensors", C.c_int32), ("param", _f * ADAM_MAX_TENSORS), ("grad", _f * ADAM_MAX_TENSORS),
+                ("exp_avg", _f * ADAM_MAX_TENSORS), ("exp_avg_sq", _f * ADAM_MAX_TENSORS), ("step", _f * ADAM_MAX_TENSORS),
+                ("numel", C.c_int64 * ADAM_MAX_TENSORS)]
+
+
 class TailProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("ctx", _f), ("x", _f), ("wd", _f), ("bd", _f),
                 ("g1", _f), ("b1", _f), ("w1", _f), ("bb1", _f), ("w2", _f), ("bb2", _f), ("g2", _f), ("b2", _f),
@@ -137,6 +146,8 @@ SYMBOLS = {
     "acattn_layer_tail_bwd": (C.c_int, [C.POINTER(TailProblem), C.POINTER(TailSaved), C.POINTER(TailBwdIO), C.c_void_p]),
     "acattn_layer_tail_bwd_partial_rows": (C.c_int32, [C.c_int32]),
     "acattn_select_layer_tail_blocks": (C.c_int, [C.c_int]),
+    "acattn_adam_step": (C.c_int, [C.POINTER(AdamGroup), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _f,
+                                   C.c_void_p]),
     "acattn_sum_rows": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "acattn_sum_rows_pair": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "acattn_mask_penalty_fwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_void_p]),

@@ -368,6 +368,24 @@ int acattn_mask_penalty_bwd_scaled_multi(const float* const* m, const float* nor
   return rc;
 }
 
+int acattn_adam_step(const acattn_adam_group* g, double lr, double beta1, double beta2, double eps, double weight_decay,
+                     int32_t* done, void* stream) {
+  if (!g || !done) return fail("group and done must be non-NULL");
+  if (g->n_tensors < 1 || g->n_tensors > ACATTN_ADAM_MAX_TENSORS) return fail("1 <= n_tensors <= ACATTN_ADAM_MAX_TENSORS");
+  int64_t blocks = 0;
+  for (int t = 0; t < g->n_tensors; ++t) {
+    if (!g->param[t] || !g->grad[t] || !g->exp_avg[t] || !g->exp_avg_sq[t] || !g->step[t])
+      return fail("param, grad, exp_avg, exp_avg_sq and step of every tensor must be non-NULL");
+    if (g->numel[t] < 1) return fail("numel must be positive");
+    blocks += (g->numel[t] + 4095) / 4096;
+  }
+  if (blocks >= (1ll << 31)) return fail("too many elements for one launch");
+  if (!(beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1)) return fail("betas must lie in [0, 1)");
+  const int rc = acattn_launch_adam_step(*g, lr, beta1, beta2, eps, weight_decay, done, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int64_t acattn_linear_wgrad_workspace_bytes(int64_t M, int32_t K, int32_t N) {
   if (M < 1 || K < 1 || N < 1) return fail("M, K, N must be positive");
   return acattn_linear_wgrad_ws_bytes(M, K, N);

@@ -282,3 +282,5 @@ int acattn_launch_zero(float* p, size_t n, hipStream_t stream);
 int acattn_launch_penalty_partial_multi(const float* const* m, int n_masks, int64_t n, float* part, hipStream_t stream);
 int acattn_launch_penalty_bwd_scaled_multi(const float* const* m, const float* norms, const float* d_loss, float scale,
                                            int64_t n, float* const* d_m, int n_masks, hipStream_t stream);
+int acattn_launch_adam_step(const acattn_adam_group& g, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, int* done, hipStream_t stream);

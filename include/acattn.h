@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 24
+#define ACATTN_ABI_VERSION 25
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -388,6 +388,27 @@ typedef struct acattn_proj_bwd_io {
 int acattn_projections_supported(int32_t H, int32_t G);
 int acattn_projections_fwd(const acattn_proj_problem* p, const acattn_proj_out* out, void* stream);
 int acattn_projections_bwd(const acattn_proj_problem* p, const acattn_proj_bwd_io* io, void* stream);
+
+/*
+ * torch.optim.Adam's update (the reference's optimizer: recbole/trainer/trainer.py:590-615, `learner: adam`) for up to
+ * ACATTN_ADAM_MAX_TENSORS parameters in one launch: amsgrad = False, maximize = False, weight decay as in Adam (added to
+ * the gradient).  Per tensor: fp32 param / grad / exp_avg / exp_avg_sq of `numel` elements and the step counter as a
+ * device float (torch's `capturable` state layout).  The counters hold the number of updates done BEFORE the call and
+ * are incremented by the launch.  `done`: a device int32 that is zero before the first call (the launch leaves it zero).
+ * The arithmetic reproduces ATen's fused kernel operation by operation (csrc/acattn_adam.hip).
+ */
+#define ACATTN_ADAM_MAX_TENSORS 64
+typedef struct acattn_adam_group {
+  int32_t n_tensors;
+  float* param[ACATTN_ADAM_MAX_TENSORS];
+  const float* grad[ACATTN_ADAM_MAX_TENSORS];
+  float* exp_avg[ACATTN_ADAM_MAX_TENSORS];
+  float* exp_avg_sq[ACATTN_ADAM_MAX_TENSORS];
+  float* step[ACATTN_ADAM_MAX_TENSORS];
+  int64_t numel[ACATTN_ADAM_MAX_TENSORS];
+} acattn_adam_group;
+int acattn_adam_step(const acattn_adam_group* g, double lr, double beta1, double beta2, double eps, double weight_decay,
+                     int32_t* done, void* stream);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);

@@ -47,7 +47,7 @@ def test_ctypes_layout_matches_c(tmp_path):
               "acattn_embed_problem": _lib.EmbedProblem, "acattn_proj_problem": _lib.ProjProblem,
               "acattn_proj_out": _lib.ProjOut, "acattn_proj_bwd_io": _lib.ProjBwdIO,
               "acattn_tail_problem": _lib.TailProblem, "acattn_tail_saved": _lib.TailSaved,
-              "acattn_tail_bwd_io": _lib.TailBwdIO}
+              "acattn_tail_bwd_io": _lib.TailBwdIO, "acattn_adam_group": _lib.AdamGroup}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "acattn.h"', 'int main(void){']
     for cname, cls in fields.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
