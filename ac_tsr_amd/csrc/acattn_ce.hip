@@ -170,6 +170,23 @@ __global__ void __launch_bounds__(256) ce_fwd_reduce_kernel(const acattn_ce_prob
 // ---------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------
+// Diagnostic builds only (-DACATTN_CE_STAMPS, tools/gpu_ce_stamps.sh): cycles per phase of the row-block loop, summed
+// over the row blocks of a wave in scalar registers and written once at the end to g_ce_stamps[wave][8].
+#ifdef ACATTN_CE_STAMPS
+__device__ unsigned long long g_ce_stamps[4096 * 8];
+#define CE_STAMP(k)                                                                \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    unsigned long long now_;                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");   \
+    if ((k) > 0) cyc_[(k) > 0 ? (k) - 1 : 0] += now_ - last_;                      \
+    last_ = now_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#else
+#define CE_STAMP(k)
+#endif
+
 // DIR = true turns the same sweep into a FORWARD that also yields the direction of d_out: lse is not known yet, so
 // every wave exponentiates against its own running maximum, the four waves of a workgroup are brought to a common
 // maximum when their [16, CH] tiles are folded, and the workgroup emits (max, sum-exp) per row next to its slab of
@@ -234,7 +251,11 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
     tgt_next = ok ? (int)P.target[row] : -1;
   };
   prefetch(0);
+#ifdef ACATTN_CE_STAMPS
+  unsigned long long cyc_[8] = {}, last_ = 0;
+#endif
   for (int rb = 0; rb < nrb; ++rb) {
+    CE_STAMP(0);
     __syncthreads();  // Hs and the exchange area of the previous block are free
 #pragma unroll
     for (int u = 0; u < HV; ++u) {
@@ -249,6 +270,7 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
     if (rb + 1 < nrb) prefetch(rb + 1);
     __syncthreads();
 
+    CE_STAMP(1);
     // logits^T tile set and dl = coef * (softmax - onehot), layout: lane = batch row, registers = items
     float hf[C::KS];
 #pragma unroll
@@ -285,6 +307,7 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         }
       }
     }
+    CE_STAMP(2);
     // (as in the forward: the catalogue-end test only in the wave that straddles the end, the exponents' arguments and the
     // scaling on register pairs -- these instructions do not run beside the fp32 MFMAs)
     if (ragged) {
@@ -326,6 +349,7 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         dl[t] = x * cf;
       }
     }
+    CE_STAMP(3);
     // d out^T (this wave's items) = E^T . dl^T : dl registers are the B operand as they stand
     f4 dh[C::DT];
 #pragma unroll
@@ -348,6 +372,7 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         for (int dt = 0; dt < C::DT; ++dt) dh[dt] = mfma16(et[k % 3][dt], dl[k >> 2][k & 3], dh[dt]);
       }
     }
+    CE_STAMP(4);
     if (WITH_TABLE_GRAD) {
       // d E (this wave's items) += dl^T . out : transpose dl through the wave's exchange area
 #pragma unroll
@@ -375,6 +400,7 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    CE_STAMP(5);
     // fold the four waves' d out tiles: each wave parks its [16][CH] tile, then every thread sums one float4
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) *(f4*)(Xw + c * C::ES + 16 * dt + 4 * g) = dh[dt];
@@ -419,7 +445,12 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         }
       }
     }
+    CE_STAMP(6);
   }
+#ifdef ACATTN_CE_STAMPS
+  if (lane == 0 && blockIdx.x * CE_NW + wave < 4096)
+    for (int k = 0; k < 8; ++k) g_ce_stamps[(blockIdx.x * CE_NW + wave) * 8 + k] = cyc_[k];
+#endif
   if (WITH_TABLE_GRAD) {
 #pragma unroll
     for (int t = 0; t < C::TILES; ++t)
@@ -708,3 +739,9 @@ int acattn_launch_ce_bwd(const acattn_ce_problem& p, const float* lse, const flo
   }
   return -1;
 }
+
+#ifdef ACATTN_CE_STAMPS
+extern "C" int acattn_debug_ce_stamps(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ce_stamps), (size_t)n_words * 8);
+}
+#endif
