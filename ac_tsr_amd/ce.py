@@ -55,7 +55,9 @@ class _FullSortCE(torch.autograd.Function):
         d_out = torch.empty_like(out)
         # the item table is not an attack parameter: its gradient is dropped in the attacked-loss pass
         want_table = ctx.needs_input_grad[1] and not ctx.state.attack_pass_only
-        d_table = torch.empty_like(table) if want_table else None
+        d_table = ctx.state.grad_buffer_for(table) if want_table else None  # data parallel: straight into the flat buffer
+        if want_table and d_table is None:
+            d_table = torch.empty_like(table)
         _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(coef), _ptr(ws), _ptr(d_out), _ptr(d_table),
                                                _stream()), "full_sort_ce_bwd")
         ctx.state.publish_table_grad(getattr(ctx, "tick", -1), table, d_table)  # (see StepState.table_grad)
@@ -105,7 +107,9 @@ class _FullSortCEDir(torch.autograd.Function):
         p = _problem(out, table, target)
         ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=out.device)
         d_out = torch.empty_like(out)
-        d_table = torch.empty_like(table) if want_table else None
+        d_table = ctx.state.grad_buffer_for(table) if want_table else None  # data parallel: straight into the flat buffer
+        if want_table and d_table is None:
+            d_table = torch.empty_like(table)
         _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_row_loss.contiguous()), _ptr(ws), _ptr(d_out),
                                                _ptr(d_table), _stream()), "full_sort_ce_bwd")
         ctx.state.publish_table_grad(getattr(ctx, "tick", -1), table, d_table)  # (see StepState.table_grad)
@@ -131,7 +135,9 @@ class _FullSortCEMean(torch.autograd.Function):
         ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=out.device)
         d_out = torch.empty_like(out)
         want_table = ctx.needs_input_grad[1] and not ctx.state.attack_pass_only
-        d_table = torch.empty_like(table) if want_table else None
+        d_table = ctx.state.grad_buffer_for(table) if want_table else None  # data parallel: straight into the flat buffer
+        if want_table and d_table is None:
+            d_table = torch.empty_like(table)
         _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_loss.contiguous()), _ptr(ws), _ptr(d_out),
                                                _ptr(d_table), _stream()), "full_sort_ce_bwd")
         ctx.state.publish_table_grad(getattr(ctx, "tick", -1), table, d_table)  # (see StepState.table_grad)

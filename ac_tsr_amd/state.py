@@ -22,7 +22,7 @@ _NO_HANDOVER = _os.environ.get("ACATTN_NO_HANDOVER") == "1"  # measurement / bis
 
 
 class StepState:
-    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "_frozen")
+    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "grad_home", "_frozen")
 
     def __init__(self, frozen: bool = False):
         object.__setattr__(self, "_frozen", False)
@@ -41,6 +41,11 @@ class StepState:
         # `tick` orders forwards: the embedding node only takes a gradient published by a loss node built after it.
         self.tick: int = 0
         self.table_grad = None  # (tick of the publishing node's forward, the table, its gradient tensor)
+        # Data parallelism keeps every gradient in one flat buffer (parallel.GradSynchronizer).  A node that produces a
+        # parameter's WHOLE gradient in one launch (the cross-entropy's dense table gradient: 99.9 % of the model's
+        # bytes) can write it there directly instead of into a fresh tensor that is copied over afterwards:
+        # {parameter data_ptr: its view of the flat buffer}, set by the trainer when it has a synchronizer.
+        self.grad_home = None
         object.__setattr__(self, "_frozen", frozen)
 
     def __setattr__(self, name, value):
@@ -52,6 +57,7 @@ class StepState:
         new = StepState()
         new.pass_mode, new.prune_dead_work, new.seed_salt = self.pass_mode, self.prune_dead_work, self.seed_salt
         new.seed_tensor = None if self.seed_tensor is None else self.seed_tensor.clone()
+        new.grad_home = None
         memo[id(self)] = new
         return new
 
@@ -102,6 +108,16 @@ class StepState:
             self.table_grad = None
             return grad
         return None
+
+    def grad_buffer_for(self, param: torch.Tensor) -> Optional[torch.Tensor]:
+        """The flat-buffer view a full gradient of `param` may be written into, or None (no synchronizer, or the parameter
+        already holds a gradient that autograd would ADD this one to)."""
+        if self._frozen or not self.grad_home or param.grad is not None:
+            return None
+        home = self.grad_home.get(param.data_ptr())
+        # a fresh tensor object on the same memory: autograd keeps a gradient without copying it only if nobody else
+        # holds the tensor object (AccumulateGrad's use_count test), and the synchronizer holds `home`
+        return None if home is None else home.view_as(home)
 
     def draw_seed(self) -> int:
         """One 63-bit seed for the library's counter RNG from torch's CPU generator (reproducible under

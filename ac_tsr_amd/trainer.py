@@ -46,6 +46,8 @@ class AttackSASRecTrainer:
         self._attack = [p for n, p in model.named_parameters() if is_attack_param(n)]
         self._others = [p for n, p in model.named_parameters() if not is_attack_param(n)]
         if grad_sync is not None:
+            # whole-parameter gradients may be written straight into the flat buffer (StepState.grad_home)
+            self.state.grad_home = {p.data_ptr(): v for p, v in zip(grad_sync.params, grad_sync.views)}
             import torch.distributed as dist
             if dist.is_initialized():  # ranks seed torch's generator alike: keep their in-kernel draws apart
                 self.state.seed_salt = (dist.get_rank(grad_sync.group) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
