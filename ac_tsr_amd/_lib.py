@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 MAX_MASKS = 8  # ACATTN_MAX_MASKS
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
@@ -37,7 +37,7 @@ class Problem(C.Structure):
         ("adversarial", C.c_int32), ("combine_option", C.c_int32), ("anneal_rate", C.c_float),
         ("two_level", C.c_int32), ("rich_combine", C.c_int32), ("rich_ratio", _f),
         ("rng_mode", C.c_int32), ("p_drop", C.c_float), ("noise", _f), ("keep_after", _f), ("keep_before", _f),
-        ("keep_mask", _f), ("seed", C.c_uint64), ("seed_device", _f),
+        ("keep_mask", _f), ("seed", C.c_uint64), ("seed_device", _f), ("affine", _f), ("gate_is_prob", C.c_int32),
     ]
 
 

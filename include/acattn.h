@@ -17,7 +17,7 @@
  *     positive = hipError_t from the launch.
  *
  * Shapes: B batch, L sequence length, H hidden size, nh heads, dh = H / nh.
- * Supported: dh in {16, 32, 64}, 1 <= L <= 208.
+ * Supported: dh in {16, 32, 64, 128}, 1 <= L <= 208.
  */
 #ifndef ACATTN_H_
 #define ACATTN_H_
@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 25
+#define ACATTN_ABI_VERSION 26
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -88,6 +88,20 @@ typedef struct acattn_problem {
   uint64_t seed;              /* COUNTER */
   const uint64_t* seed_device; /* COUNTER, optional: *seed_device (device memory) is added to `seed` when the kernel
                                   starts -- lets a captured hipGraph draw fresh randomness on every replay */
+  /* ---- optional per-row products of the PRODUCER of q / k / gate (ABI 26) ------------------------------------------
+   * Both are O(L H) work that belongs with the projections; the core re-derives them 2-4 times per sequence when they
+   * are absent (once per head for the gate, once per query block for the key halves).  acattn_projections_fwd writes
+   * both; acattn_spatial_affines() computes `affine` from q, k and the calibrator parameters for any other producer. */
+  const float* affine;  /* NULL, or [B,nh,4,LP] with LP = 16*ceil(L/16): the rank-1 halves of the two spatial affines
+                           of layers.py:705-708, affine(q_i || k_j) = q_i.w[:dh] + k_j.w[dh:] + b:
+                             plane 0 [i] = -log2(e) * (q_i . w_order[:dh] + b_order)     (sigmoid(o) = 1/(1+exp2(p0+p2)))
+                             plane 1 [i] =             q_i . w_dist[:dh]  + b_dist
+                             plane 2 [j] = -log2(e) *  k_j . w_order[dh:]
+                             plane 3 [j] =             k_j . w_dist[dh:]
+                           entries L..LP-1 must be finite (zeros). */
+  int32_t gate_is_prob; /* non-zero: `gate_logits` holds sigmoid(gate(mixed_query)) (layers.py:887: one sigmoid per
+                           (b, i, j), shared by the heads) instead of the logits; d gate_logits of the backward is
+                           still the gradient of the LOGITS */
 } acattn_problem;
 
 typedef struct acattn_fwd_out {

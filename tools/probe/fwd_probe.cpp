@@ -38,6 +38,7 @@ struct Variant {
   abi_fn abi = nullptr;
   sel_fn sel = nullptr;
   int which = 0;
+  bool pre = false;  // "lib.so+pre": the problem carries the producer's affine planes and gate probabilities (ABI 26)
   int operator()(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t st) const {
     if (direct) return direct(p, o, st);
     sel(which);
@@ -48,21 +49,29 @@ struct Variant {
 struct Set {
   acattn_problem p;
   acattn_fwd_out o;
+  acattn_problem ppre;  // the same problem with affine planes + gate probabilities
 };
 
-static float* dev_randn(size_t n, std::mt19937& g, float scale = 1.f) {
+static float* dev_randn(size_t n, std::mt19937& g, float scale = 1.f, std::vector<float>* keep = nullptr) {
   std::vector<float> h(n);
   std::normal_distribution<float> d(0.f, scale);
   for (auto& x : h) x = d(g);
   float* p;
   CK(hipMalloc(&p, n * 4));
   CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice));
+  if (keep) keep->swap(h);
+  return p;
+}
+static float* dev_copy(const std::vector<float>& h) {
+  float* p;
+  CK(hipMalloc(&p, h.size() * 4));
+  CK(hipMemcpy(p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   return p;
 }
 
 int main(int argc, char** argv) {
   int B = 512, L = 50, H = 64, nh = 2, adv = 1, rounds = 12, iters = 60, nsets = 6, stamps = 0, full_len = 0, balance = 0, causal = 1;
-  float p_drop = 0.5f;
+  float p_drop = 0.5f, wscale = 0.02f;
   std::vector<std::string> libs;
   for (int i = 1; i < argc; ++i) {
     auto is = [&](const char* s) { return !strcmp(argv[i], s) && i + 1 < argc; };
@@ -79,13 +88,15 @@ int main(int argc, char** argv) {
     else if (is("-balance")) balance = atoi(argv[++i]);
     else if (is("-causal")) causal = atoi(argv[++i]);
     else if (is("-pdrop")) p_drop = atof(argv[++i]);
+    else if (is("-wscale")) wscale = atof(argv[++i]);
     else libs.push_back(argv[i]);
   }
   if (libs.empty()) { fprintf(stderr, "no libs\n"); return 2; }
   std::vector<Variant> fns;
-  for (auto& l : libs) {
-    std::string path = l;
+  for (auto l : libs) {
     Variant v;
+    if (l.size() > 4 && l.substr(l.size() - 4) == "+pre") { v.pre = true; l = l.substr(0, l.size() - 4); }
+    std::string path = l;
     const size_t colon = l.rfind(':');
     if (colon != std::string::npos && colon + 2 == l.size()) { path = l.substr(0, colon); v.which = l[colon + 1] - '0'; }
     void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -104,10 +115,11 @@ int main(int argc, char** argv) {
   }
   std::mt19937 g(42);
   const int dh = H / nh;
-  float* w_order = dev_randn(2 * dh, g, 0.02f);
-  float* w_dist = dev_randn(2 * dh, g, 0.02f);
-  float* b_order = dev_randn(1, g, 0.02f);
-  float* b_dist = dev_randn(1, g, 0.02f);
+  std::vector<float> hwo, hwd, hbo, hbd;
+  float* w_order = dev_randn(2 * dh, g, wscale, &hwo);
+  float* w_dist = dev_randn(2 * dh, g, wscale, &hwd);
+  float* b_order = dev_randn(1, g, wscale, &hbo);
+  float* b_dist = dev_randn(1, g, wscale, &hbd);
   float* scalar = dev_randn(1, g, 1.f);
   const size_t n_lh = (size_t)B * L * H, n_ll = (size_t)B * L * L, n_m = (size_t)B * nh * L * L;
   const size_t n_waves = (size_t)B * nh * 4;
@@ -120,7 +132,8 @@ int main(int argc, char** argv) {
     acattn_fwd_out o;
     memset(&o, 0, sizeof o);
     p.B = B; p.L = L; p.H = H; p.n_heads = nh;
-    p.q = dev_randn(n_lh, g); p.k = dev_randn(n_lh, g); p.v = dev_randn(n_lh, g);
+    std::vector<float> hq, hk, hg;
+    p.q = dev_randn(n_lh, g, 1.f, &hq); p.k = dev_randn(n_lh, g, 1.f, &hk); p.v = dev_randn(n_lh, g);
     std::vector<uint8_t> kv((size_t)B * L);
     std::uniform_int_distribution<int> ld(1, L);
     std::vector<int> lens(B);
@@ -145,14 +158,37 @@ int main(int argc, char** argv) {
     p.adversarial = adv; p.two_level = 1; p.rng_mode = ACATTN_RNG_COUNTER; p.p_drop = p_drop; p.seed = 1234 + s;
     float* cc; CK(hipMalloc(&cc, n_lh * 4)); o.ctx_calibrated = cc;
     if (adv) {
-      p.qa = dev_randn(n_lh, g); p.ka = dev_randn(n_lh, g); p.gate_logits = dev_randn(n_ll, g);
+      p.qa = dev_randn(n_lh, g); p.ka = dev_randn(n_lh, g); p.gate_logits = dev_randn(n_ll, g, 1.f, &hg);
       p.combine_option = ACATTN_COMBINE_GATE;
       float *ca, *m, *st;
       CK(hipMalloc(&ca, n_lh * 4)); CK(hipMalloc(&m, n_m * 4)); CK(hipMalloc(&st, (size_t)B * nh * L * ACATTN_NSTAT * 4));
       o.ctx_attacked = ca; o.attack_mask = m; o.row_stats = st;
     }
     if (stamps) p.noise = (const float*)stamp_buf;
-    sets[s] = Set{p, o};
+    acattn_problem pp = p;
+    {  // what the producer of q / k / gate would hand over (acattn.h: affine, gate_is_prob)
+      const int LP = 16 * ((L + 15) / 16);
+      const double l2e = 1.4426950408889634;
+      std::vector<float> aff((size_t)B * nh * 4 * LP, 0.f);
+      for (int b = 0; b < B; ++b)
+        for (int h = 0; h < nh; ++h)
+          for (int i = 0; i < L; ++i) {
+            double ao = hbo[0], ad = hbd[0], co = 0, cd = 0;
+            for (int d = 0; d < dh; ++d) {
+              const double qv = hq[((size_t)b * L + i) * H + h * dh + d], kv2 = hk[((size_t)b * L + i) * H + h * dh + d];
+              ao += qv * hwo[d]; ad += qv * hwd[d]; co += kv2 * hwo[dh + d]; cd += kv2 * hwd[dh + d];
+            }
+            float* pl = &aff[((size_t)b * nh + h) * 4 * LP];
+            pl[i] = (float)(-l2e * ao); pl[LP + i] = (float)ad; pl[2 * LP + i] = (float)(-l2e * co); pl[3 * LP + i] = (float)cd;
+          }
+      pp.affine = dev_copy(aff);
+      if (adv) {
+        for (auto& x : hg) x = 1.f / (1.f + expf(-x));
+        pp.gate_logits = dev_copy(hg);
+        pp.gate_is_prob = 1;
+      }
+    }
+    sets[s] = Set{p, o, pp};
   }
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -160,14 +196,24 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   // correctness vs variant 0 on set 0
   std::vector<float> ref_c(n_lh), ref_m(adv ? n_m : 0), cur_c(n_lh), cur_m(adv ? n_m : 0);
+  const size_t n_st = adv ? (size_t)B * nh * L * ACATTN_NSTAT : 0;
+  std::vector<float> ref_a(adv ? n_lh : 0), cur_a(adv ? n_lh : 0), ref_s(n_st), cur_s(n_st);
   for (size_t v = 0; v < fns.size(); ++v) {
     CK(hipMemsetAsync(sets[0].o.ctx_calibrated, 0xFF, n_lh * 4, st));
-    int rc = fns[v](sets[0].p, sets[0].o, st);
+    int rc = fns[v](fns[v].pre ? sets[0].ppre : sets[0].p, sets[0].o, st);
     CK(hipStreamSynchronize(st));
     if (rc) { fprintf(stderr, "variant %zu launch rc=%d\n", v, rc); return 3; }
     CK(hipMemcpy(cur_c.data(), sets[0].o.ctx_calibrated, n_lh * 4, hipMemcpyDeviceToHost));
     if (adv) CK(hipMemcpy(cur_m.data(), sets[0].o.attack_mask, n_m * 4, hipMemcpyDeviceToHost));
-    if (v == 0) { ref_c = cur_c; ref_m = cur_m; }
+    if (adv) {
+      CK(hipMemcpy(cur_a.data(), sets[0].o.ctx_attacked, n_lh * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(cur_s.data(), sets[0].o.row_stats, n_st * 4, hipMemcpyDeviceToHost));
+    }
+    if (v == 0) { ref_c = cur_c; ref_m = cur_m; ref_a = cur_a; ref_s = cur_s; }
+    double da = 0, ds = 0;
+    for (size_t i = 0; i < cur_a.size(); ++i) da = std::max(da, (double)fabsf(cur_a[i] - ref_a[i]));
+    for (size_t i = 0; i < cur_s.size(); ++i) ds = std::max(ds, (double)fabsf(cur_s[i] - ref_s[i]));
+    printf("variant %zu   max|ctx_att - v0| = %.3e  max|row_stats - v0| = %.3e\n", v, da, ds);
     double dc = 0, dm = 0, sc = 0; size_t nan = 0;
     for (size_t i = 0; i < n_lh; ++i) { if (!(cur_c[i] == cur_c[i])) ++nan; dc = std::max(dc, (double)fabsf(cur_c[i] - ref_c[i])); sc += fabs(cur_c[i]); }
     for (size_t i = 0; i < cur_m.size(); ++i) dm = std::max(dm, (double)fabsf(cur_m[i] - ref_m[i]));
@@ -177,7 +223,7 @@ int main(int argc, char** argv) {
   for (int r = -1; r < rounds; ++r) {
     for (size_t v = 0; v < fns.size(); ++v) {
       CK(hipEventRecord(e0, st));
-      for (int i = 0; i < iters; ++i) fns[v](sets[i % nsets].p, sets[i % nsets].o, st);
+      for (int i = 0; i < iters; ++i) fns[v](fns[v].pre ? sets[i % nsets].ppre : sets[i % nsets].p, sets[i % nsets].o, st);
       CK(hipEventRecord(e1, st));
       CK(hipEventSynchronize(e1));
       float ms;
@@ -215,6 +261,15 @@ int main(int argc, char** argv) {
       auto q = [](std::vector<double>& x, double f) { return x.empty() ? 0.0 : x[(size_t)(f * (x.size() - 1))]; };
       printf("  stamp %2d: since launch p10 %7.0f p50 %7.0f p90 %7.0f max %7.0f | since prev p10 %6.0f p50 %6.0f p90 %6.0f max %6.0f (n=%zu)\n", k,
              q(abs_t, .1), q(abs_t, .5), q(abs_t, .9), q(abs_t, 1.0), q(d, .1), q(d, .5), q(d, .9), q(d, 1.0), abs_t.size());
+    }
+    // streaming kernels: one wave per block, blocks ordered by rank (rank 0 = the heaviest query block under the causal mask)
+    for (int rk = 0; rk < 4; ++rk) {
+      std::vector<double> tot, st;
+      for (size_t w = rk * (n_waves / 4); w < (rk + 1) * (n_waves / 4); ++w)
+        if (h[w * 16] && h[w * 16 + stamps - 1]) { tot.push_back((double)(h[w * 16 + stamps - 1] - h[w * 16])); st.push_back((double)(h[w * 16] - tmin)); }
+      std::sort(tot.begin(), tot.end()); std::sort(st.begin(), st.end());
+      if (!tot.empty()) printf("  rank %d: start p50 %7.0f p90 %7.0f | lifetime p10 %7.0f p50 %7.0f p90 %7.0f\n", rk, st[st.size() / 2], st[(size_t)(0.9 * (st.size() - 1))],
+                               tot[(size_t)(0.1 * (tot.size() - 1))], tot[tot.size() / 2], tot[(size_t)(0.9 * (tot.size() - 1))]);
     }
     // by wave index inside the workgroup (query block): p50 of the total
     for (int wv = 0; wv < 4; ++wv) {
