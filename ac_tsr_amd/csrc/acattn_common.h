@@ -190,6 +190,42 @@ __device__ __forceinline__ RngGroup rng_group_half(const RngKey key, uint32_t ro
   return o;
 }
 
+// The same draw as rng_group_half with the four normals as two register pairs already multiplied by `scale`
+// ((cos, sin) * (radius * scale): one packed multiply per pair; the product differs from (radius * cos) * scale in
+// the last bit at most).
+typedef float acattn_f2 __attribute__((ext_vector_type(2)));
+struct RngDraw {
+  acattn_f2 n01, n23;
+  uint32_t keep_after, keep_mask, keep_before;
+};
+__device__ __forceinline__ RngDraw rng_draw_half(const RngKey key, uint32_t row_id, uint32_t grp, float scale) {
+  uint32_t x = (row_id * 64u + grp) ^ key.a;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  x += key.b;
+  const uint32_t wn[2] = {x, rng_word(x, 0x68E31DA4u, 0x9E3779B1u)};
+  RngDraw o;
+  acattn_f2 n[2];
+#pragma unroll
+  for (int pair = 0; pair < 2; ++pair) {  // Box-Muller
+    const float u1 = fmaf((float)(wn[pair] >> 16), 1.0f / 65536.0f, 0.5f / 65536.0f);  // (0, 1)
+    const float u2 = (float)(wn[pair] & 0xFFFFu) * (1.0f / 65536.0f);                  // [0, 1) revolutions
+    const float rad = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u1) * (-2.0f * 0.69314718055994530942f)) * scale;
+    acattn_f2 cs = {__builtin_amdgcn_cosf(u2), __builtin_amdgcn_sinf(u2)};
+    asm("" : "+v"(cs));
+    n[pair] = cs * rad;
+  }
+  o.n01 = n[0];
+  o.n23 = n[1];
+  const uint32_t w2 = rng_word(x, 0xB5297A4Du, 0x85EBCA77u);
+  o.keep_after = (w2 >> 4) & 0xFu;
+  o.keep_mask = (w2 >> 12) & 0xFu;
+  o.keep_before = (w2 >> 20) & 0xFu;
+  return o;
+}
+
 // keep bits -> what dropout multiplies by
 __device__ __forceinline__ f4 keep_scale4(uint32_t bits, float keep_scale) {
   f4 s;

@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 name=$1; shift
 mkdir -p $R/tools/tmp_libs
 C=$R/ac_tsr_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I$R/include -I$C -Wno-unused-result "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -I$R/include -I$C -Wno-unused-result $NANFLAG "$@" \
   $C/acattn_fwd_stream.hip $C/acattn_fwd_stream_dh16.hip $C/acattn_fwd_stream_dh32.hip $C/acattn_fwd_stream_dh64.hip \
   -o $R/tools/tmp_libs/libfwd_$name.so
 echo built $R/tools/tmp_libs/libfwd_$name.so
