@@ -76,11 +76,13 @@ LN_BWD_GRID = 512
 class ProjProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("H", C.c_int32), ("G", C.c_int32), ("x", _f), ("wq", _f), ("bq", _f), ("wk", _f),
                 ("bk", _f), ("wv", _f), ("bv", _f), ("waq", _f), ("baq", _f), ("wak", _f), ("bak", _f), ("wg", _f),
-                ("bg", _f)]
+                ("bg", _f), ("w_order", _f), ("b_order", _f), ("w_dist", _f), ("b_dist", _f), ("n_heads", C.c_int32),
+                ("L", C.c_int32)]
 
 
 class ProjOut(C.Structure):
-    _fields_ = [("mq", _f), ("mk", _f), ("mv", _f), ("qa", _f), ("ka", _f), ("gate", _f)]
+    _fields_ = [("mq", _f), ("mk", _f), ("mv", _f), ("qa", _f), ("ka", _f), ("gate", _f), ("affine", _f),
+                ("gate_prob", C.c_int32)]
 
 
 class ProjBwdIO(C.Structure):
@@ -130,6 +132,7 @@ SYMBOLS = {
     "acattn_fwd_algorithmic_bytes": (C.c_int64, [C.POINTER(Problem)]),
     "acattn_calibrated_attention_fwd": (C.c_int, [C.POINTER(Problem), C.POINTER(FwdOut), C.c_void_p]),
     "acattn_calibrated_attention_bwd": (C.c_int, [C.POINTER(Problem), C.POINTER(BwdIO), C.c_void_p]),
+    "acattn_spatial_affines": (C.c_int, [C.POINTER(Problem), _f, C.c_void_p]),
     "acattn_full_sort_ce_workspace_bytes": (C.c_int64, [C.POINTER(CeProblem)]),
     "acattn_full_sort_ce_fwd": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, C.c_void_p]),
     "acattn_full_sort_ce_fwd_dir": (C.c_int, [C.POINTER(CeProblem), _f, _f, _f, _f, C.c_void_p]),

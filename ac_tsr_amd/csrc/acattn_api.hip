@@ -91,6 +91,17 @@ int acattn_calibrated_attention_fwd(const acattn_problem* p, const acattn_fwd_ou
   return rc;
 }
 
+int acattn_spatial_affines(const acattn_problem* p, float* affine, void* stream) {
+  if (!p || !affine) return fail("problem and affine must be non-NULL");
+  if (p->B < 1 || p->L < 1 || p->H < 1 || p->n_heads < 1 || p->H % p->n_heads != 0 || (p->H / p->n_heads) % 4 != 0)
+    return fail("spatial affines: bad shape");
+  if (!p->q || !p->k || !p->w_order || !p->b_order || !p->w_dist || !p->b_dist)
+    return fail("spatial affines need q, k and both affines' parameters");
+  const int rc = acattn_launch_spatial_affines(*p, affine, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int acattn_calibrated_attention_bwd(const acattn_problem* p, const acattn_bwd_io* io, void* stream) {
   if (int rc = check_problem(p)) return rc;
   if (!io) return fail("io is NULL");
@@ -202,6 +213,11 @@ int acattn_projections_fwd(const acattn_proj_problem* p, const acattn_proj_out* 
   if (int rc = check_proj(p)) return rc;
   if (!out || !out->mq || !out->mk || !out->mv || !out->qa || !out->ka) return fail("projections: outputs must be non-NULL");
   if ((p->wg != nullptr) != (out->gate != nullptr)) return fail("projections: gate output goes with the gate parameters");
+  if (out->affine) {
+    if (!p->w_order || !p->b_order || !p->w_dist || !p->b_dist) return fail("projections: affine planes need the spatial calibrator's parameters");
+    if (p->n_heads < 1 || p->H % p->n_heads != 0 || (p->H / p->n_heads) % 16 != 0) return fail("projections: affine planes need a head size that is a multiple of 16");
+    if (p->L < 1 || p->rows % p->L != 0) return fail("projections: affine planes need rows = B * L");
+  }
   const int rc = acattn_launch_proj_fwd(*p, *out, (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;

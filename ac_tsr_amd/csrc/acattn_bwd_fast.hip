@@ -484,13 +484,9 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
 #pragma unroll
         for (int r = 0; r < 4; ++r) ex1[r] = ex2(a1[r]);
         const f4 v2 = (p * ex1) * kLog2e + (mk4 - lse_v2);
-        const f4 eg = load_seg(grow, t) * (-kLog2e);
-        f4 gt;
+        const f4 gt = gate_value(load_seg(grow, t), P.gate_is_prob);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          Ac[t][r] = ex2(v2[r]) * okf;
-          gt[r] = fast_rcp(1.0f + ex2(eg[r]));
-        }
+        for (int r = 0; r < 4; ++r) Ac[t][r] = ex2(v2[r]) * okf;
         const f4 w2 = (gt * (p - Ac[t]) + Ac[t]) * kLog2e + (mk4 - lse_w2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Aw[t][r] = ex2(w2[r]) * okf;
@@ -504,10 +500,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
 #pragma unroll
         for (int r = 0; r < 4; ++r) sa[r] = ((keepA >> (4 * t + r)) & 1u) ? keep_scale : 0.f;
         const f4 p = tS[t] * sa;
-        const f4 eg = load_seg(grow, t) * (-kLog2e);
-        f4 gt;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gt[r] = fast_rcp(1.0f + ex2(eg[r]));
+        const f4 gt = gate_value(load_seg(grow, t), P.gate_is_prob);
         const f4 dw = Aw[t] * (dAw[t] - dc);                       // = d A_g
         if (full) store_seg(IO.dgate_logits + prow, t, dw * (p - Ac[t]) * (gt * (1.0f - gt)));
         dPa[t] += gt * dw;

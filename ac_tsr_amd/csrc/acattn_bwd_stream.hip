@@ -63,6 +63,7 @@ struct Row {
 struct Consts {
   float inv_sqrt, scale2, nc2, s2, sc, keep_scale, p_drop;
   bool has_drop, causal;
+  int gate_is_prob;  // acattn_problem.gate_is_prob
   RngKey rkey;
 };
 
@@ -132,12 +133,9 @@ __device__ __forceinline__ void tile_elementwise(const RowT& R, const Consts& K,
     T.ex1[r] = ex2(a1[r]);
   }
   const f4 av = (T.P * T.ex1) * kLog2e - R.lv2;  // layers.py:920-921
-  const f4 eg = gl * (-kLog2e);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    T.Ac[r] = and_bits(ex2(av[r]), T.eb[r]);
-    T.gt[r] = fast_rcp(1.0f + ex2(eg[r]));  // layers.py:887
-  }
+  for (int r = 0; r < 4; ++r) T.Ac[r] = and_bits(ex2(av[r]), T.eb[r]);
+  T.gt = gate_value(gl, K.gate_is_prob);  // layers.py:887
   const f4 aw = (T.gt * (T.P - T.Ac) + T.Ac) * kLog2e - R.lw2;  // layers.py:888, 925
 #pragma unroll
   for (int r = 0; r < 4; ++r) T.Aw[r] = and_bits(ex2(aw[r]), T.eb[r]);
@@ -309,6 +307,7 @@ __device__ __forceinline__ Consts make_consts(const acattn_problem& P, int DH) {
   K.has_drop = P.p_drop > 0.f;
   K.keep_scale = K.has_drop ? fast_rcp(1.0f - P.p_drop) : 1.0f;
   K.causal = P.causal != 0;
+  K.gate_is_prob = P.gate_is_prob;
   K.rkey = rng_key(P.seed + (P.seed_device ? *P.seed_device : 0ull));
   return K;
 }

@@ -72,6 +72,16 @@ __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_log
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 
+// The gate of the calibrated branch, g = sigmoid(gate(mixed_query)) (layers.py:887), from what acattn_problem.gate_logits
+// holds: the logits, or -- acattn_problem.gate_is_prob (wave-uniform) -- g itself, computed once by the producer.
+__device__ __forceinline__ f4 gate_value(const f4 gl, int is_prob) {
+  if (is_prob) return gl;
+  f4 gt;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) gt[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(gl[r] * -1.44269504088896340736f));
+  return gt;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Counter-based randomness (ACATTN_RNG_COUNTER).  One call yields, for the 4 consecutive keys
 // j0..j0+3 of one query row, 4 standard normals (Box-Muller) and the dropout keep decisions of the
@@ -300,6 +310,7 @@ int acattn_fwd_kernel_choice(int which);
 int acattn_bwd_kernel_choice(int which);
 int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p);
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
+int acattn_launch_spatial_affines(const acattn_problem& p, float* affine, hipStream_t stream);
 int acattn_launch_rng(int B, int nh, int L, uint64_t seed, float p_drop, float* noise, uint8_t* keep_after,
                       uint8_t* keep_mask, uint8_t* keep_before, hipStream_t stream);
 int64_t acattn_ce_ws_bytes(const acattn_ce_problem& p);

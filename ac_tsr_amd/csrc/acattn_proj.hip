@@ -127,6 +127,50 @@ __device__ __forceinline__ void set_rows(const f4 (&b)[DT], f4 (&acc)[NB][DT]) {
 }
 
 
+// Rank-1 halves of the spatial calibrator's affines (layers.py:705-708) for the rows of this wave, from the projected
+// rows still in the accumulators (v[nb][nt][r] = value[row c][feature 16 nt + 4 g + r]):
+//     plane P0     [i] = -log2(e) (v_i . w_order[woff : woff + dh] + bias_o)
+//     plane P0 + 1 [i] =           v_i . w_dist [woff : woff + dh] + bias_d
+// into affine[b, head, plane, i] (acattn_problem.affine).  Query halves: woff = 0, biases, P0 = 0; key halves: woff =
+// dh, no bias, P0 = 2.
+template <int DT, int NB>
+__device__ __forceinline__ void write_affine(const f4 (&v)[NB][DT], const Rows<NB>& W, const acattn_proj_problem& P, float* affine,
+                                             int woff, float bias_o, float bias_d, int P0, int c, int g) {
+  constexpr float kL2e = 1.44269504088896340736f;
+  const int nh = P.n_heads, dh = (16 * DT) / nh, tph = dh >> 4;  // 16-feature tiles per head
+  const int LP = ((P.L + 15) >> 4) << 4;
+  f4 wo[DT], wd[DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt) {
+    const int f0 = woff + (16 * nt) % dh + 4 * g;
+    wo[nt] = *(const f4*)(P.w_order + f0);
+    wd[nt] = *(const f4*)(P.w_dist + f0);
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int row = W.row[nb], b = row / P.L, i = row - b * P.L;
+    float so = 0.f, sd = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < DT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        so = fmaf(v[nb][nt][r], wo[nt][r], so);
+        sd = fmaf(v[nb][nt][r], wd[nt][r], sd);
+      }
+      if ((nt + 1) % tph == 0) {  // head complete (wave-uniform)
+        const float o = quad_sum(so), d = quad_sum(sd);
+        if (g == 0 && W.ok[nb]) {
+          float* pl = affine + ((size_t)(b * nh + nt / tph) * 4 + P0) * LP + i;
+          pl[0] = -kL2e * (o + bias_o);
+          pl[LP] = d + bias_d;
+        }
+        so = 0.f;
+        sd = 0.f;
+      }
+    }
+  }
+}
+
 template <int H, int NB>
 __global__ void __launch_bounds__(64) proj_fwd_kernel(const acattn_proj_problem P, const acattn_proj_out O) {
   constexpr int DT = H / 16;
@@ -147,6 +191,7 @@ __global__ void __launch_bounds__(64) proj_fwd_kernel(const acattn_proj_problem 
   set_rows<DT, NB>(ba, m);
   product<DT, NB>(wa, xb, m);  // mq
   store_rows<DT, NB>(O.mq, W, g, m);
+  if (O.affine) write_affine<DT, NB>(m, W, P, O.affine, 0, P.b_order[0], P.b_dist[0], 0, c, g);
   load_weight<DT>(P.wk, H, H, c, g, wa);
   load_bias<DT>(P.bk, g, ba);
   PIN_ORDER();
@@ -185,7 +230,8 @@ __global__ void __launch_bounds__(64) proj_fwd_kernel(const acattn_proj_problem 
           for (int nb = 0; nb < NB; ++nb) ga[nb][r & 1] = mfma16(cw[t][r], m[nb][t][r], ga[nb][r & 1]);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const f4 v = ga[nb][0] + ga[nb][1];
+        f4 v = ga[nb][0] + ga[nb][1];
+        if (O.gate_prob) v = gate_value(v, 0);  // sigmoid once per (b, i, j): the heads share it (layers.py:887)
         // the lane's four logits are consecutive in the row: one (dword-aligned) 16-byte store, not four scattered ones
         const int j0 = 16 * nt + 4 * g;
         float* dst = O.gate + (size_t)W.row[nb] * P.G + j0;
@@ -214,6 +260,7 @@ __global__ void __launch_bounds__(64) proj_fwd_kernel(const acattn_proj_problem 
   set_rows<DT, NB>(ba, m);
   product<DT, NB>(wa, xb, m);  // mk
   store_rows<DT, NB>(O.mk, W, g, m);
+  if (O.affine) write_affine<DT, NB>(m, W, P, O.affine, H / P.n_heads, 0.f, 0.f, 2, c, g);
   load_weight<DT>(P.wv, H, H, c, g, wa);
   load_bias<DT>(P.bv, g, ba);
   PIN_ORDER();

@@ -348,3 +348,53 @@ int acattn_launch_zero(float* p, size_t n, hipStream_t stream) {
   hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, p, n);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// acattn_spatial_affines: the affine planes of acattn_problem.affine from q, k and the calibrator parameters, for a
+// producer that is not acattn_projections_fwd (which writes them from its accumulators).  One lane per (b, head, i):
+// four dot products of length dh; padding entries [L, LP) are written as zeros.  A few MB in, ~1 MB out.
+namespace {
+__global__ void __launch_bounds__(256) spatial_affines_kernel(const acattn_problem P, float* affine) {
+  const int L = P.L, H = P.H, nh = P.n_heads, dh = H / nh;
+  const int LP = ((L + 15) >> 4) << 4;
+  const long long total = (long long)P.B * nh * LP;
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= total) return;
+  const int i = (int)(idx % LP);
+  const long long bh = idx / LP;
+  const int h = (int)(bh % nh);
+  const long long b = bh / nh;
+  float* pl = affine + bh * 4 * LP + i;
+  if (i >= L) {
+    pl[0] = pl[LP] = pl[2 * LP] = pl[3 * LP] = 0.f;
+    return;
+  }
+  const float* q = P.q + ((size_t)b * L + i) * H + h * dh;
+  const float* k = P.k + ((size_t)b * L + i) * H + h * dh;
+  float ao = 0.f, ad = 0.f, co = 0.f, cd = 0.f;
+  for (int d = 0; d < dh; d += 4) {
+    const f4 qv = *(const f4*)(q + d), kv = *(const f4*)(k + d);
+    const f4 wo = *(const f4*)(P.w_order + d), wd = *(const f4*)(P.w_dist + d);
+    const f4 wok = *(const f4*)(P.w_order + dh + d), wdk = *(const f4*)(P.w_dist + dh + d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ao = fmaf(qv[e], wo[e], ao);
+      ad = fmaf(qv[e], wd[e], ad);
+      co = fmaf(kv[e], wok[e], co);
+      cd = fmaf(kv[e], wdk[e], cd);
+    }
+  }
+  constexpr float kL2e = 1.44269504088896340736f;
+  pl[0] = -kL2e * (ao + P.b_order[0]);
+  pl[LP] = ad + P.b_dist[0];
+  pl[2 * LP] = -kL2e * co;
+  pl[3 * LP] = cd;
+}
+}  // namespace
+
+int acattn_launch_spatial_affines(const acattn_problem& p, float* affine, hipStream_t stream) {
+  const long long total = (long long)p.B * p.n_heads * (((p.L + 15) >> 4) << 4);
+  hipLaunchKernelGGL(spatial_affines_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, affine);
+  return (int)hipGetLastError();
+}
+

@@ -173,9 +173,11 @@ class AttackRTransformerLayer(nn.Module):
         is position-wise, so it then runs on the selected rows alone (the models read one position per sequence of the
         last layer, abstract_recommender.py:130-134; AcBERT4Rec the masked positions, acbert4rec.py:219-225)."""
         att = self.attack_attention
-        mq, mk, mv, qa, ka, gate_logits, hidden_res = projections(
+        cal = att.calibrator_params()
+        mq, mk, mv, qa, ka, gate_logits, hidden_res, extras = projections(
             hidden_states, att.query, att.key, att.value, att.attack_query_transform, att.attack_key_transform,
-            self.gate if self.combine_option == 'gate' else None, attack_upstream=_attack_upstream)
+            self.gate if self.combine_option == 'gate' else None, attack_upstream=_attack_upstream,
+            spatial=(cal.get("w_order"), cal.get("b_order"), cal.get("w_dist"), cal.get("b_dist"), att.num_attention_heads))
         cfg = self._config()
         core_rnd = None
         if _rnd is not None:
@@ -187,7 +189,8 @@ class AttackRTransformerLayer(nn.Module):
         ctx_att, ctx_cal, attack_mask, probs = ops.calibrated_attention(
             mq, mk, mv, qa, ka, gate_logits, attention_mask, cfg, p_drop=p_drop, rnd=core_rnd, want_probs=want_probs,
             seed_tensor=state_of(self).seed_tensor if core_rnd is None else None, read_rows=_rows,
-            attack_upstream=_attack_upstream, state=state_of(self), rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None), **att.calibrator_params())
+            attack_upstream=_attack_upstream, state=state_of(self), rich_ratio=getattr(self, "rich_calibrated_combine_ratio", None),
+            **extras, **cal)
         residual = hidden_res  # hidden_states, via the projection node (its backward launch takes the residual gradient)
         if _rows is not None:
             index = _rows.unsqueeze(-1).expand(-1, -1, hidden_states.shape[-1])

@@ -141,6 +141,8 @@ class _Projections(torch.autograd.Function):
 
 # measurement switch (bench.py --projections library): route supported sizes through the hipBLASLt node as well
 FUSED_PROJECTIONS = True
+# measurement / test switch: let the fused launch hand affine planes and gate probabilities to the attention core
+PRODUCER_EXTRAS = True
 
 
 class _FusedProjections(torch.autograd.Function):
@@ -161,7 +163,13 @@ class _FusedProjections(torch.autograd.Function):
         return p
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg, attack_upstream, state):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, waq, baq, wak, bak, wg, bg, attack_upstream, state, spatial=None):
+        """`spatial` = (w_order, b_order, w_dist, b_dist, n_heads) or None.  With it (and a [B, L, H] input) the launch
+        also writes what the attention core would otherwise re-derive per head / per query block: the rank-1 halves of
+        the two spatial affines (acattn_problem.affine) and sigmoid(gate) in place of the gate logits
+        (acattn_problem.gate_is_prob).  The gate output then HOLDS PROBABILITIES while the gradient that comes back for
+        it is still the gradient of the logits (include/acattn.h: acattn_bwd_io.dgate_logits) -- an internal edge
+        between this node and the attention node, not something a caller sees."""
         import ctypes as C
         from . import _lib
         from .ops import _ptr, _stream
@@ -172,19 +180,32 @@ class _FusedProjections(torch.autograd.Function):
         gate = x.new_empty(*x.shape[:-1], p.G) if wg is not None else None
         out = _lib.ProjOut()
         out.mq, out.mk, out.mv, out.qa, out.ka, out.gate = (_ptr(t) for t in (mq, mk, mv, qa, ka, gate))
+        affine = None
+        keep = []
+        if spatial is not None and x.dim() == 3:
+            w_order, b_order, w_dist, b_dist, n_heads = spatial
+            B, L, H = x.shape
+            affine = _affine_workspace(x.device, B, n_heads, L)
+            keep = [t.detach().reshape(-1).contiguous() for t in (w_order, b_order, w_dist, b_dist)]
+            p.w_order, p.b_order, p.w_dist, p.b_dist = (_ptr(t) for t in keep)
+            p.n_heads, p.L = n_heads, L
+            out.affine = _ptr(affine)
+            out.gate_prob = 1 if gate is not None else 0
         _lib.check(_lib.load().acattn_projections_fwd(C.byref(p), C.byref(out), _stream()), "projections_fwd")
         ctx.save_for_backward(x, mq, mk, *(t if t is not None else x.new_empty(0) for t in params))
         ctx.has_gate = wg is not None
         ctx.attack_upstream = attack_upstream
         ctx.state = state
         ctx.set_materialize_grads(False)
+        if affine is not None:
+            ctx.mark_non_differentiable(affine)
         # x again, as an output of this node: the layer hands it to its tails as the residual (layers.py:683), so their
         # d_x arrives HERE and the backward launch starts dx from it (acattn_proj_bwd_io.dx_init) instead of autograd
         # adding the two [rows, H] gradients of x with an elementwise launch per layer and walk
-        return mq, mk, mv, qa, ka, gate, x.view_as(x)
+        return mq, mk, mv, qa, ka, gate, x.view_as(x), affine
 
     @staticmethod
-    def backward(ctx, dmq, dmk, dmv, dqa, dka, dgate, d_res=None):
+    def backward(ctx, dmq, dmk, dmv, dqa, dka, dgate, d_res=None, _d_affine=None):
         import ctypes as C
         from . import _lib
         from .ops import _ptr, _stream, linear_wgrad_grouped
@@ -230,13 +251,33 @@ class _FusedProjections(torch.autograd.Function):
         if jobs:
             for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs])):
                 grads[slot - 1], grads[slot] = gw, gb
-        return (dx, *grads, None, None)
+        return (dx, *grads, None, None, None)
 
 
-def projections(x, query, key, value, attack_query, attack_key, gate=None, attack_upstream=True):
-    """(mq, mk, mv, qa, ka, gate_logits or None, x_res) of one encoder layer; see _Projections.  `attack_upstream=False`
-    tells the node that nothing that produced `x` holds attack transforms (the first encoder layer).  `x_res` is `x`
-    for the residual connections of the layer (see _FusedProjections.forward; plain `x` on the other paths)."""
+_AFFINE_WS = {}
+
+
+def _affine_workspace(device, B, n_heads, L):
+    """[B, n_heads, 4, LP] zeros, ONE buffer per shape: the projections launch of a layer writes entries [0, L) of every
+    plane, the attention launch right behind it on the same stream reads them, nobody else ever does (the backward
+    recomputes from q, k and the parameters) -- so the layers of a model share it, and the padding entries [L, LP),
+    which the kernels never write but do load, stay the zeros they were allocated as."""
+    key = (device, B, n_heads, L)
+    ws = _AFFINE_WS.get(key)
+    if ws is None:
+        if len(_AFFINE_WS) > 16:
+            _AFFINE_WS.clear()
+        ws = _AFFINE_WS[key] = torch.zeros(B, n_heads, 4, 16 * ((L + 15) // 16), device=device, dtype=torch.float32)
+    return ws
+
+
+def projections(x, query, key, value, attack_query, attack_key, gate=None, attack_upstream=True, spatial=None):
+    """(mq, mk, mv, qa, ka, gate_logits or None, x_res, extras) of one encoder layer; see _Projections.
+    `attack_upstream=False` tells the node that nothing that produced `x` holds attack transforms (the first encoder
+    layer).  `x_res` is `x` for the residual connections of the layer (see _FusedProjections.forward; plain `x` on the
+    other paths).  `spatial` = (w_order, b_order, w_dist, b_dist, n_heads): the single-launch path then also produces
+    the affine planes and hands the gate over as probabilities; `extras` = {'affine': tensor, 'gate_is_prob': bool}
+    says what it did (empty on the other paths) and goes to ops.calibrated_attention as keyword arguments."""
     node = _Projections if torch.is_grad_enabled() else None
     if x.is_cuda and FUSED_PROJECTIONS and x.dtype == torch.float32 and all(
             m.bias is not None for m in (query, key, value, attack_query, attack_key) + ((gate,) if gate is not None else ())):
@@ -245,12 +286,19 @@ def projections(x, query, key, value, attack_query, attack_key, gate=None, attac
             node = _FusedProjections  # the single launch serves evaluation (no_grad) as well
     if not x.is_cuda or node is None:
         mq, mk, mv = query(x), key(x), value(x)
-        return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None), x
-    out = node.apply(x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
-                     attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
-                     gate.weight if gate is not None else None, gate.bias if gate is not None else None,
-                     attack_upstream, state_of(query))
-    return out if len(out) == 7 else (*out, x)
+        return mq, mk, mv, attack_query(mq), attack_key(mk), (gate(mq) if gate is not None else None), x, {}
+    args = (x, query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
+            attack_query.weight, attack_query.bias, attack_key.weight, attack_key.bias,
+            gate.weight if gate is not None else None, gate.bias if gate is not None else None,
+            attack_upstream, state_of(query))
+    if node is _FusedProjections:
+        if not PRODUCER_EXTRAS or (spatial is not None and any(t is None for t in spatial[:4])):
+            spatial = None
+        *out, affine = node.apply(*args, spatial)
+        extras = {} if affine is None else {"affine": affine, "gate_is_prob": gate is not None}
+        return (*out, extras)
+    out = node.apply(*args)
+    return (*out, x, {})
 
 
 class _FullSortScores(torch.autograd.Function):

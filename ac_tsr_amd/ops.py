@@ -79,7 +79,8 @@ def _stream() -> C.c_void_p:
 
 
 def _fill_problem(q, k, v, qa, ka, gate_logits, mask, w_order, b_order, w_dist, b_dist, scalar, rich_ratio,
-                  cfg: AttentionConfig, p_drop: float, rnd, seed: int, keepalive: list, seed_tensor=None) -> Problem:
+                  cfg: AttentionConfig, p_drop: float, rnd, seed: int, keepalive: list, seed_tensor=None,
+                  gate_is_prob: bool = False, affine=None) -> Problem:
     B, L, H = q.shape
     prob = Problem()
     prob.B, prob.L, prob.H, prob.n_heads = B, L, H, cfg.n_heads
@@ -102,6 +103,11 @@ def _fill_problem(q, k, v, qa, ka, gate_logits, mask, w_order, b_order, w_dist, 
             # same failure as the reference's broadcast at layers.py:888 when seq_length != L
             raise RuntimeError(f"The size of tensor a ({gate_logits.shape[-1]}) must match the size of tensor b ({L})")
         prob.gate_logits = _ptr(gate_logits)
+        prob.gate_is_prob = int(bool(gate_is_prob))
+    if affine is not None:
+        _need_cuda("affine", affine)
+        assert affine.shape == (B, cfg.n_heads, 4, 16 * ((L + 15) // 16)), "affine must be [B, n_heads, 4, 16*ceil(L/16)]"
+        prob.affine = _ptr(affine)
     # mask
     if isinstance(mask, StructuredMask):
         kv = mask.key_valid
@@ -170,7 +176,7 @@ class _CalibratedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, mask,
                 cfg: AttentionConfig, p_drop: float, rnd, seed: int, want_probs: bool, seed_tensor=None,
-                read_rows=None, attack_upstream=True, state=_DEFAULT_STATE):
+                read_rows=None, attack_upstream=True, state=_DEFAULT_STATE, gate_is_prob=False, affine=None):
         lib = _lib.load()
         B, L, H = q.shape
         ctx.attack_upstream = attack_upstream
@@ -192,7 +198,8 @@ class _CalibratedAttention(torch.autograd.Function):
         wo = w_order.reshape(-1) if w_order is not None else None
         wd = w_dist.reshape(-1) if w_dist is not None else None
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
-                             p_drop, rnd, seed, keep, seed_tensor)
+                             p_drop, rnd, seed, keep, seed_tensor, gate_is_prob, affine)
+        ctx.gate_is_prob = gate_is_prob  # the backward reads the same tensor the same way; the planes are forward-only
         out = FwdOut()
         ctx_cal = torch.empty_like(q)
         out.ctx_calibrated = _ptr(ctx_cal)
@@ -230,7 +237,7 @@ class _CalibratedAttention(torch.autograd.Function):
         wo = w_order.reshape(-1) if w_order is not None else None
         wd = w_dist.reshape(-1) if w_dist is not None else None
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, ctx.mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
-                             ctx.p_drop, ctx.rnd, ctx.seed, keep, ctx.seed_tensor)
+                             ctx.p_drop, ctx.rnd, ctx.seed, keep, ctx.seed_tensor, ctx.gate_is_prob)
         io = BwdIO()
         io.attack_mask, io.row_stats = _ptr(M), _ptr(stats)
         d_att = None if d_att is None else d_att.contiguous()
@@ -262,7 +269,7 @@ class _CalibratedAttention(torch.autograd.Function):
         io.attack_only = int(attack_only)
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
         if attack_only:
-            return (None, None, None, dqa, dka) + (None,) * 17
+            return (None, None, None, dqa, dka) + (None,) * 19
         if dgate_part is not None and dgate_part.shape[1] > 1 and part.shape[0] < 4096:
             # the gate is shared by the heads (layers.py:887 unsqueeze(1)): its per-head gradients and the parameter
             # partials are summed by ONE launch
@@ -284,7 +291,7 @@ class _CalibratedAttention(torch.autograd.Function):
         g_sc = small[2:3].view_as(scalar) if w_dist is not None else None
         g_rr = small[3:4].view_as(rich_ratio) if rich_ratio is not None else None
         return (dq, dk, dv, dqa, dka, dgate, g_wo, g_bo, g_wd, g_bd, g_sc, g_rr, None, None, None, None, None, None, None,
-                None, None, None)
+                None, None, None, None, None)
 
 
 def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfig, *, w_order=None, b_order=None,
@@ -292,7 +299,7 @@ def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfi
                          rnd: Optional[ExplicitRandomness] = None, seed: Optional[int] = None,
                          want_probs: bool = False, seed_tensor: Optional[torch.Tensor] = None,
                          read_rows: Optional[torch.Tensor] = None, attack_upstream: bool = True,
-                         state=_DEFAULT_STATE):
+                         state=_DEFAULT_STATE, gate_is_prob: bool = False, affine: Optional[torch.Tensor] = None):
     """Fused core of one AttackRTransformerLayer between the projections and the output dense.
 
     `attack_upstream=False` declares that nothing that produced q, k, v holds attack transforms (first encoder layer):
@@ -304,6 +311,11 @@ def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfi
     of each sequence: the backward then skips query blocks that cannot carry a cotangent (a speed hint; results are
     the same because the skipped rows' cotangents are zero).
 
+    `gate_is_prob` / `affine`: what the producer of q, k and the gate already computed (acattn_problem.gate_is_prob,
+    .affine; linear.projections returns both as `extras`): `gate_logits` then holds sigmoid(gate(mixed_query)) -- the
+    gradient returned for it is still that of the logits -- and `affine` [B, n_heads, 4, 16*ceil(L/16)] the rank-1
+    halves of the spatial calibrator's affines.
+
     Returns (ctx_attacked [B,L,H] | None, ctx_calibrated [B,L,H], M [B,h,L,L] | None, probs dict).
     """
     if rnd is None and seed is None:
@@ -312,7 +324,7 @@ def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfi
     # into the graph, the tensor is what changes between replays (trainer.enable_graph)
     outs = _CalibratedAttention.apply(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar,
                                       rich_ratio, mask, cfg, p_drop, rnd, seed or 0, want_probs, seed_tensor, read_rows,
-                                      attack_upstream, state)
+                                      attack_upstream, state, gate_is_prob, affine)
     names = ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")
     probs = {n: t for n, t in zip(names, outs[3:]) if t is not None}
     return outs[0], outs[1], outs[2], probs

@@ -96,7 +96,11 @@ def model_config(a):
 # --------------------------------------------------------------------------------------------------
 # kernel roofline: direct C-ABI launches on torch's current stream, HIP events around the timed region
 # --------------------------------------------------------------------------------------------------
-def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
+def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None, full_length=False):
+    """The forward kernel as the training step launches it: q, k, v, qa, ka, the gate as the projections launch hands
+    it over (probabilities, acattn_problem.gate_is_prob) and the affine planes it writes (acattn_problem.affine; here
+    produced by acattn_spatial_affines).  `full_length`: every sequence has all L items (SURVEY 8d's worst case) instead
+    of item_length ~ U{1..L}."""
     nsets = nsets or int(os.environ.get("ACTSR_BENCH_NSETS", "6"))  # 6 sets = 372 MB > 256 MiB Infinity Cache
     from ac_tsr_amd import _lib, ops
     lib = _lib.load()
@@ -113,6 +117,8 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
         q, k, v, qa, ka = (torch.randn(B, L, H, generator=gen).to(device) for _ in range(5))
         gl = torch.randn(B, L, L, generator=gen).to(device)
         lens = torch.randint(1, L + 1, (B,), generator=gen)
+        if full_length:
+            lens = torch.full((B,), L)
         kv = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(device)
         ctx_a, ctx_c = torch.empty_like(q), torch.empty_like(q)
         M = torch.empty(B, nh, L, L, device=device)
@@ -131,6 +137,15 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
             p.qa, p.ka, p.gate_logits = qa.data_ptr(), ka.data_ptr(), gl.data_ptr()
             p.combine_option = _lib.COMBINE["gate"]
             o.ctx_attacked, o.attack_mask, o.row_stats = ctx_a.data_ptr(), M.data_ptr(), stats.data_ptr()
+        if not os.environ.get("ACTSR_BENCH_NO_EXTRAS"):
+            affine = torch.empty(B, nh, 4, 16 * ((L + 15) // 16), device=device)
+            _lib.check(lib.acattn_spatial_affines(C.byref(p), affine.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "spatial_affines")
+            p.affine = affine.data_ptr()
+            if adversarial:
+                gl = torch.sigmoid(gl)
+                p.gate_logits, p.gate_is_prob = gl.data_ptr(), 1
+            keep.append(affine)
         sets.append((p, o))
         keep.append((q, k, v, qa, ka, gl, kv, ctx_a, ctx_c, M, stats))
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -157,7 +172,9 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
     dh = H // nh
     flavour = "true" if adversarial else "false"
     # the automatic choice of acattn_calibrated_attention_fwd for this configuration (csrc/acattn_fwd.hip)
-    kernel_name = "acattn_fwd_stream_kernel<%d,%d,%s>" % (dh, 4 if L <= 64 else 13, flavour)
+    # template arguments: head size, key tiles per row, adversarial calibrator, p_drop == 0.5, producer extras
+    kernel_name = "acattn_fwd_stream_kernel<%d,%d,%s,true,%s>" % (
+        dh, 4 if L <= 64 else 13, flavour, "false" if os.environ.get("ACTSR_BENCH_NO_EXTRAS") else "true")
     if a.fwd_kernel == "staged" and L <= 64:
         kernel_name = ("acattn_fwd_dma_kernel<%d,%s>" if L > 48 else "acattn_fwd_fast_kernel<%d,%s>") % (dh, flavour)
     elif a.fwd_kernel == "general":
@@ -166,7 +183,7 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
     achieved = alg / (best * 1e-6) / 1e9
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "fwd_pmc_latest.json")
-    if os.path.exists(pmc) and (B, L, H, nh) == (512, 50, 64, 2):
+    if os.path.exists(pmc) and (B, L, H, nh) == (512, 50, 64, 2) and not full_length:
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and shape
         # (FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 FETCH_SIZE x2 correction applied)
         k = json.load(open(pmc))["kernels"].get(kernel_name)
@@ -177,6 +194,7 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": kernel_name,
             "contract": "A" if adversarial else "A'", "algorithmic_bytes_per_launch": alg,
+            "item_length": "all L" if full_length else "U{1..L}",
             "avg_launch_us": round(best, 2), "launches_timed": 3 * iters, "buffer_sets": nsets}
 
 
@@ -274,6 +292,7 @@ def main():
 
     if a.kernel_only:
         out = {"roofline": kernel_roofline(a, device, True, a.kernel_iters),
+               "roofline_full_length": kernel_roofline(a, device, True, a.kernel_iters, full_length=True),
                "roofline_spatial_only": kernel_roofline(a, device, False, a.kernel_iters)}
         print(json.dumps(out), flush=True)
         return
@@ -364,6 +383,9 @@ def main():
                     "note": "same step computing also the provably dead work the reference computes (DESIGN.md 5)"}},
         }
         res["roofline"] = kernel_roofline(a, device, True, a.kernel_iters)
+        # the same kernel when every sequence has all L items ("also report the all-L worst case"): the
+        # algorithmic bytes are the same, no key tile past the last item can be skipped
+        res["roofline_full_length"] = kernel_roofline(a, device, True, a.kernel_iters, full_length=True)
         res["roofline_spatial_only"] = kernel_roofline(a, device, False, a.kernel_iters)
         if world == 1 and not a.no_cpu_baseline and a.model == "ACSASRec":
             res["cpu_baseline"] = cpu_baseline(a, init_state, a.cpu_steps)

@@ -379,11 +379,20 @@ typedef struct acattn_proj_problem {
   const float *waq, *baq;    /* attack_attention.attack_query_transform */
   const float *wak, *bak;    /* attack_attention.attack_key_transform */
   const float *wg, *bg;      /* gate [G,H], [G]; or NULL */
+  /* ABI 26, only read when acattn_proj_out.affine is set: the spatial calibrator's parameters (layers.py:636-640), the
+   * head count and the sequence length (rows = B * L, row r sits at position r % L of sequence r / L) */
+  const float *w_order, *b_order, *w_dist, *b_dist; /* [2*dh], [1], [2*dh], [1] */
+  int32_t n_heads, L;
 } acattn_proj_problem;
 
 typedef struct acattn_proj_out {
   float *mq, *mk, *mv, *qa, *ka; /* [rows,H] each */
   float* gate;                   /* [rows,G] or NULL */
+  /* ABI 26: what the attention core would otherwise re-derive per head / per query block (acattn_problem.affine,
+   * .gate_is_prob) */
+  float* affine;      /* NULL, or [B,nh,4,LP], LP = 16*ceil(L/16): entries [0, L) of every plane are written, the
+                         padding entries are left alone (allocate the buffer zeroed once; they must be finite) */
+  int32_t gate_prob;  /* non-zero: `gate` receives sigmoid(logits) instead of the logits */
 } acattn_proj_out;
 
 /* Cotangents in (each may be NULL = zero), gradients out (each may be NULL = not wanted):
@@ -441,6 +450,11 @@ int64_t acattn_fwd_algorithmic_bytes(const acattn_problem* p);
  *   the two P.V products and head merge                recbole/model/layers.py:677-680
  */
 int acattn_calibrated_attention_fwd(const acattn_problem* p, const acattn_fwd_out* out, void* stream);
+
+/* The affine planes of acattn_problem.affine ([B,nh,4,16*ceil(L/16)], padding written as zeros) from p->q, p->k and the
+ * spatial calibrator's parameters (recbole/model/layers.py:705-708 in rank-1 form), for a producer of q / k other than
+ * acattn_projections_fwd.  Reads only B, L, H, n_heads, q, k, w_order, b_order, w_dist, b_dist of *p. */
+int acattn_spatial_affines(const acattn_problem* p, float* affine, void* stream);
 
 /* Backward of the above (what autograd derives for the same op chain in the reference). May be
  * called any number of times for one forward (the trainer walks the graph twice:

@@ -523,7 +523,7 @@ def bert_full_sort_predict(item_seq: Tensor, item_seq_len: Tensor, P: Dict[str, 
 def core_from_projected(mq: Tensor, mk: Tensor, mv: Tensor, qa: Tensor, ka: Tensor, gate_logits: Optional[Tensor],
                         mask: Tensor, w_order, b_order, w_dist, b_dist, scalar, cfg: EncoderCfg,
                         noise: Tensor, keep_after=None, keep_mask=None, keep_before=None, anneal_rate: float = 1.0,
-                        rich_ratio=None):
+                        rich_ratio=None, materialize: bool = True):
     """Everything between the projections and the output dense, following layers.py:695-740,
     664-672, 917-936, 677-680 on already-projected tensors.
 
@@ -541,7 +541,9 @@ def core_from_projected(mq: Tensor, mk: Tensor, mv: Tensor, qa: Tensor, ka: Tens
         "attack_attention.scalar": scalar,
     }
     raw = torch.matmul(q, k.transpose(-1, -2))
-    e_o, e_d = spatial_errors(q, k, p, cfg, materialize=True)
+    # materialize=False: the affine over (q_i || k_j) in its rank-1 form (the [B,h,L,L,2dh] tensor of layers.py:705-708 is
+    # 655 MB at the benchmark's batch); tests/test_oracle_golden.py pins both forms to the reference
+    e_o, e_d = spatial_errors(q, k, p, cfg, materialize=materialize)
     pa = cfg.attn_dropout_prob
     after = _drop(torch.softmax((raw + e_o + e_d) / math.sqrt(dh) + mask, dim=-1), keep_after, pa)
     before = _drop(torch.softmax(raw / math.sqrt(dh) + mask, dim=-1), keep_before, pa)

@@ -1,0 +1,233 @@
+"""GPU suite (-m gpu): the kernels bench.py TIMES, at the shape it times them, against the ORACLE in one hop.
+
+Round 2 pinned the tuned kernels to the general HIP kernels at B = 512 and the general kernels to the oracle on the
+B <= 4 goldens.  Here the streaming forward (recbole/model/layers.py:686-742, 657-674, 898-951 fused) and the tuned
+backward kernels (row-resident, one-row, mask-only split; the trainer's cotangent patterns of
+recbole/trainer/trainer.py:672-686) run at B = 512, L = 50, H = 64, 2 heads, causal, p_drop 0.5, item_length ~
+U{1..L} -- and at BASELINE configs[3]'s shape through the streaming backward -- and are compared with
+oracle/ac_tsr_ref.py::core_from_projected (and its autograd) fed the kernels' own counter-RNG draws
+(acattn_rng_materialize).  Also: the producer's affine planes / gate probabilities (ABI 26) in the forward kernel, in
+the projections launch and in acattn_spatial_affines.
+
+Tolerances: M 5e-6, contexts 1e-4 (north_star: logits within 1e-4); gradients 2e-3 of each tensor's largest magnitude
+(the oracle differentiates the materialised formulation, the kernels the rank-1 / log-normaliser formulation)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+import ac_tsr_amd as A
+from ac_tsr_amd import _lib, linear, ops
+from ac_tsr_amd.state import StepState
+from oracle import ac_tsr_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _problem(B, L, H, nh, seed, causal=True, scale=0.3, left_pad=False):
+    g = torch.Generator().manual_seed(seed)
+    t = {k: torch.randn(B, L, H, generator=g) for k in ("q", "k", "v", "qa", "ka")}
+    t["gl"] = torch.randn(B, L, L, generator=g)
+    dh = H // nh
+    for k, shp in (("w_order", (1, 2 * dh)), ("b_order", (1,)), ("w_dist", (1, 2 * dh)), ("b_dist", (1,)), ("scalar", (1,))):
+        t[k] = scale * torch.randn(*shp, generator=g)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    kv = (torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8)
+    if left_pad:
+        kv[1] = 1 - kv[1]
+    return t, kv, lens, g
+
+
+def _oracle_mask(kv, causal):
+    B, L = kv.shape
+    item_seq = kv.to(torch.int64)  # any non-zero id is a real item (abstract_recommender.py:137)
+    return O.attention_mask(item_seq, bidirectional=not causal)
+
+
+def _affine_planes(t, nh):
+    """The producer's affine planes, in fp64 on the host (include/acattn.h: acattn_problem.affine)."""
+    B, L, H = t["q"].shape
+    dh = H // nh
+    LP = 16 * ((L + 15) // 16)
+    q = t["q"].double().view(B, L, nh, dh).permute(0, 2, 1, 3)
+    k = t["k"].double().view(B, L, nh, dh).permute(0, 2, 1, 3)
+    wo, wd = t["w_order"].double().reshape(-1), t["w_dist"].double().reshape(-1)
+    l2e = 1.0 / math.log(2.0)
+    planes = torch.zeros(B, nh, 4, LP, dtype=torch.float64)
+    planes[:, :, 0, :L] = -l2e * (q @ wo[:dh] + t["b_order"].double())
+    planes[:, :, 1, :L] = q @ wd[:dh] + t["b_dist"].double()
+    planes[:, :, 2, :L] = -l2e * (k @ wo[dh:])
+    planes[:, :, 3, :L] = k @ wd[dh:]
+    return planes.float()
+
+
+@pytest.mark.parametrize("B,L,H,nh,causal", [(512, 50, 64, 2, True), (512, 50, 64, 2, False), (8, 200, 128, 4, True)],
+                         ids=["bench_shape", "bench_shape_bidirectional", "cfg4_shape"])
+@pytest.mark.parametrize("extras", [False, True], ids=["in_kernel", "producer_extras"])
+def test_streaming_forward_matches_oracle_in_one_hop(B, L, H, nh, causal, extras):
+    t, kv, lens, g = _problem(B, L, H, nh, seed=101, causal=causal)
+    dev = {k: v.to(DEV) for k, v in t.items()}
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
+    mask = A.StructuredMask(kv.to(DEV), causal=causal)
+    kw = {k: dev[k] for k in ("w_order", "b_order", "w_dist", "b_dist", "scalar")}
+    seed, p_drop = 20251, 0.5
+    gate = dev["gl"]
+    if extras:
+        kw.update(affine=_affine_planes(t, nh).to(DEV), gate_is_prob=True)
+        gate = torch.sigmoid(dev["gl"])
+    lib = _lib.load()
+    lib.acattn_select_forward_kernel(_lib.FWD_STREAM)
+    try:
+        ctx_a, ctx_c, M, _ = A.calibrated_attention(dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], gate, mask, cfg,
+                                                    p_drop=p_drop, seed=seed, **kw)
+    finally:
+        lib.acattn_select_forward_kernel(_lib.FWD_AUTO)
+    rnd = A.materialize_randomness(B, nh, L, seed, p_drop, DEV)
+    ocfg = O.EncoderCfg(n_layers=1, n_heads=nh, hidden_size=H, inner_size=4 * H, combine_option="gate", seq_length=L,
+                        attn_dropout_prob=p_drop)
+    with torch.no_grad():
+        ref = O.core_from_projected(t["q"], t["k"], t["v"], t["qa"], t["ka"], t["gl"], _oracle_mask(kv, causal),
+                                    t["w_order"], t["b_order"], t["w_dist"], t["b_dist"], t["scalar"], ocfg,
+                                    rnd.noise.cpu(), keep_after=rnd.keep_after.cpu().float(),
+                                    keep_mask=rnd.keep_mask.cpu().float(), materialize=False)
+    assert (M.cpu() - ref["M"]).abs().max().item() <= 5e-6
+    assert (ctx_a.cpu() - ref["ctx_attacked"]).abs().max().item() <= 1e-4
+    assert (ctx_c.cpu() - ref["ctx_calibrated"]).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("pattern", ["all", "calibrated_read_row", "attacked_read_row_plus_mask"])
+@pytest.mark.parametrize("B,L,H,nh", [(512, 50, 64, 2), (8, 200, 128, 4)], ids=["bench_shape", "cfg4_shape"])
+def test_tuned_backward_matches_oracle_autograd_in_one_hop(B, L, H, nh, pattern):
+    """`all`: every cotangent dense (the first layer's calibrated pass; row-resident kernel at L = 50, the streaming
+    pair at L = 200).  `calibrated_read_row`: one context row per sequence (the last layer, pass 1: one-row kernel).
+    `attacked_read_row_plus_mask`: the attacked context at the read row + a dense mask cotangent (the last layer, pass 2:
+    mask-only blocks + the one-row chain)."""
+    t, kv, lens, g = _problem(B, L, H, nh, seed=202)
+    seed, p_drop = 777, 0.5
+    rows = (lens - 1).view(-1, 1)
+    rnd = A.materialize_randomness(B, nh, L, seed, p_drop, DEV)
+    cot = {"ctx_attacked": torch.zeros(B, L, H), "ctx_calibrated": torch.zeros(B, L, H), "M": torch.zeros(B, nh, L, L)}
+    row_cot = torch.randn(B, 1, H, generator=g)
+    idx = rows.unsqueeze(-1).expand(-1, -1, H)
+    if pattern == "all":
+        cot = {k: torch.randn(v.shape, generator=g) for k, v in cot.items()}
+    elif pattern == "calibrated_read_row":
+        cot["ctx_calibrated"].scatter_(1, idx, row_cot)
+    else:
+        cot["ctx_attacked"].scatter_(1, idx, row_cot)
+        cot["M"] = torch.randn(B, nh, L, L, generator=g) * 1e-3  # the penalty's cotangent is small and dense
+    names = ["q", "k", "v", "qa", "ka", "gl", "w_order", "b_order", "w_dist", "b_dist", "scalar"]
+    cpu = {k: t[k].clone().requires_grad_(True) for k in names}
+    ocfg = O.EncoderCfg(n_layers=1, n_heads=nh, hidden_size=H, inner_size=4 * H, combine_option="gate", seq_length=L,
+                        attn_dropout_prob=p_drop)
+    ref = O.core_from_projected(cpu["q"], cpu["k"], cpu["v"], cpu["qa"], cpu["ka"], cpu["gl"], _oracle_mask(kv, True),
+                                cpu["w_order"], cpu["b_order"], cpu["w_dist"], cpu["b_dist"], cpu["scalar"], ocfg,
+                                rnd.noise.cpu(), keep_after=rnd.keep_after.cpu().float(),
+                                keep_mask=rnd.keep_mask.cpu().float(), materialize=False)
+    want = dict(zip(names, torch.autograd.grad(sum((ref[k] * cot[k]).sum() for k in cot), [cpu[k] for k in names])))
+
+    dev = {k: t[k].to(DEV).requires_grad_(True) for k in names}
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
+    mask = A.StructuredMask(kv.to(DEV), causal=True)
+    read_rows = None if pattern == "all" else rows.to(DEV)
+    ctx_a, ctx_c, M, _ = A.calibrated_attention(dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev["gl"], mask, cfg,
+                                                p_drop=p_drop, seed=seed, read_rows=read_rows,
+                                                **{k: dev[k] for k in names[6:]})
+    loss = (ctx_a * cot["ctx_attacked"].to(DEV)).sum() + (ctx_c * cot["ctx_calibrated"].to(DEV)).sum() + \
+        (M * cot["M"].to(DEV)).sum()
+    got = dict(zip(names, torch.autograd.grad(loss, [dev[k] for k in names])))
+    for k in names:
+        scale = want[k].abs().max().item()
+        err = (got[k].cpu() - want[k]).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-7, (k, err, scale)
+
+
+@pytest.mark.parametrize("B,L,H,nh", [(6, 50, 64, 2), (3, 37, 64, 4), (2, 200, 128, 4), (2, 130, 256, 4)])
+def test_spatial_affines_entry_point(B, L, H, nh):
+    t, kv, lens, g = _problem(B, L, H, nh, seed=5)
+    dev = {k: v.to(DEV).contiguous() for k, v in t.items()}
+    p = _lib.Problem()
+    p.B, p.L, p.H, p.n_heads = B, L, H, nh
+    p.q, p.k = dev["q"].data_ptr(), dev["k"].data_ptr()
+    wo, wd = dev["w_order"].reshape(-1).contiguous(), dev["w_dist"].reshape(-1).contiguous()
+    p.w_order, p.b_order, p.w_dist, p.b_dist = wo.data_ptr(), dev["b_order"].data_ptr(), wd.data_ptr(), dev["b_dist"].data_ptr()
+    LP = 16 * ((L + 15) // 16)
+    out = torch.full((B, nh, 4, LP), float("nan"), device=DEV)
+    _lib.check(_lib.load().acattn_spatial_affines(C.byref(p), out.data_ptr(), ops._stream()), "spatial_affines")
+    want = _affine_planes(t, nh)
+    assert torch.isfinite(out).all()  # the padding entries are written (zeros)
+    assert (out.cpu() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("B,L,nh", [(32, 50, 2), (5, 37, 4), (512, 50, 2), (3, 200, 1)])
+def test_projections_launch_hands_over_affine_planes_and_gate_probabilities(B, L, nh):
+    """acattn_projections_fwd with acattn_proj_out.affine / .gate_prob: the planes from the rows still in its
+    accumulators, sigmoid(gate) in place of the logits; everything else and every gradient as without them (the gate
+    cotangent that comes back is the gradient of the LOGITS: include/acattn.h)."""
+    H = 64
+    g = torch.Generator().manual_seed(B + L)
+    r = lambda *s: torch.randn(*s, generator=g)
+    t = dict(x=r(B, L, H))
+    for n in ("q", "k", "v", "aq", "ak"):
+        t["w" + n], t["b" + n] = 0.2 * r(H, H), 0.1 * r(H)
+    t["wg"], t["bg"] = 0.2 * r(L, H), 0.1 * r(L)
+    dh = H // nh
+    sp = dict(w_order=0.3 * r(1, 2 * dh), b_order=0.3 * r(1), w_dist=0.3 * r(1, 2 * dh), b_dist=0.3 * r(1))
+    W = ("wq", "bq", "wk", "bk", "wv", "bv", "waq", "baq", "wak", "bak", "wg", "bg")
+    dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
+    spd = tuple(v.to(DEV) for v in sp.values()) + (nh,)
+    plain = linear._FusedProjections.apply(dev["x"], *(dev[n] for n in W), True, StepState())
+    extra = linear._FusedProjections.apply(dev["x"], *(dev[n] for n in W), True, StepState(), spd)
+    assert plain[7] is None and extra[7] is not None
+    for a, b in zip(plain[:5], extra[:5]):
+        assert torch.equal(a, b)
+    assert (extra[5] - torch.sigmoid(plain[5])).abs().max().item() <= 2e-6
+    mq, mk = plain[0].detach().cpu(), plain[1].detach().cpu()
+    want = _affine_planes(dict(q=mq, k=mk, **sp), nh)
+    got = extra[7].cpu()
+    assert (got - want).abs().max().item() <= 3e-5 * max(1.0, want.abs().max().item())
+    assert got[..., L:].abs().max().item() == 0.0 if got.shape[-1] > L else True
+    cot = [r(B, L, H).to(DEV) for _ in range(5)] + [r(B, L, L).to(DEV)]
+    names = ["x"] + list(W)
+    ga = torch.autograd.grad(sum((o * c).sum() for o, c in zip(plain[:6], cot)), [dev[n] for n in names])
+    gb = torch.autograd.grad(sum((o * c).sum() for o, c in zip(extra[:6], cot)), [dev[n] for n in names])
+    for n, a, b in zip(names, ga, gb):
+        assert torch.equal(a, b), n
+
+
+def test_encoder_layer_equals_itself_without_producer_extras():
+    """One AttackRTransformerLayer, training mode, counter RNG: with the projections launch handing the planes and the
+    gate probabilities to the core (the default) and with the core deriving both itself -- outputs and gradients."""
+    torch.manual_seed(3)
+    B, L, H = 64, 50, 64
+    layer = A.AttackRTransformerLayer(n_heads=2, hidden_size=H, intermediate_size=256, hidden_dropout_prob=0.0,
+                                      attn_dropout_prob=0.5, hidden_act="gelu", layer_norm_eps=1e-12, combine_option="gate",
+                                      use_order=True, use_distance=True, two_level=True, rich_calibrated_combine="none",
+                                      seq_length=L).to(DEV).train()
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            if "affine" in n or "scalar" in n:
+                p.copy_(0.3 * torch.randn_like(p))
+    x = torch.randn(B, L, H, device=DEV, requires_grad=True)
+    lens = torch.randint(1, L + 1, (B,))
+    mask = A.StructuredMask((torch.arange(L)[None, :] < lens[:, None]).to(torch.uint8).to(DEV), causal=True)
+    res = []
+    for on in (True, False):
+        linear.PRODUCER_EXTRAS = on
+        try:
+            torch.manual_seed(11)  # the kernels' seeds are drawn from torch's CPU generator
+            att, cal, M, _ = layer(x, mask)
+            # random cotangents (sums of squares of LayerNorm outputs are nearly constant: their gradients are noise)
+            gc = torch.Generator().manual_seed(5)
+            c1, c2, c3 = (torch.randn(t_.shape, generator=gc).to(DEV) for t_ in (att, cal, M))
+            loss = (att * c1).sum() + (cal * c2).sum() + (M * c3).sum()
+            res.append((att, cal, M, torch.autograd.grad(loss, [x] + list(layer.parameters()))))
+        finally:
+            linear.PRODUCER_EXTRAS = True
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert (a - b).abs().max().item() <= 2e-5
+    for (n, _), a, b in zip([("x", None)] + list(layer.named_parameters()), res[0][3], res[1][3]):
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-5, n

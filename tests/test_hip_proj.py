@@ -111,7 +111,7 @@ def test_residual_gradient_enters_the_backward_launch(rows):
     dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
     res_cot = torch.randn(rows, H, generator=torch.Generator().manual_seed(9)).to(DEV)
     outs = linear._FusedProjections.apply(dev["x"], *(dev[n] for n in W), True, StepState())
-    assert len(outs) == 7 and outs[6].data_ptr() == dev["x"].data_ptr()
+    assert len(outs) == 8 and outs[6].data_ptr() == dev["x"].data_ptr()
     loss = sum((o * cot[k].to(DEV)).sum() for k, o in zip(OUT, outs))
     base, = torch.autograd.grad(loss, [dev["x"]], retain_graph=True)
     both, = torch.autograd.grad(loss + (outs[6] * res_cot).sum(), [dev["x"]], retain_graph=True)
