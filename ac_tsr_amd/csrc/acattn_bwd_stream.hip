@@ -720,7 +720,9 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
   const int lane = threadIdx.x;
   const size_t rowbase = (size_t)b * L, bh = (size_t)b * nh + h;
   const int hoff = h * DH;
-  const int i = (int)IO.read_rows[b];  // n_read_rows == 1
+  // n_read_rows == 1.  Positions outside [0, L) (item_seq_len == 0 gives -1) are a caller error the reference's gather
+  // answers with an index error; here they are clamped, so the launch at least stays inside the sequence's memory
+  const int i = min(max((int)IO.read_rows[b], 0), L - 1);
   const KeyFlags F = load_key_flags(P.key_valid, rowbase, L, nT, lane);
   const Consts K = make_consts(P, DH);
 
@@ -947,7 +949,9 @@ int launch_stream(const acattn_problem& p, const acattn_bwd_io& io, float* ws, h
   const size_t rows = (size_t)p.B * p.n_heads;
   if (!io.attack_only) {  // the parameter partial rows are accumulated with atomics: start from zero
     // (acattn_launch_zero, not hipMemsetAsync: see acattn_util.hip)
-    auto zero = [&](float* ptr, size_t n) { (void)acattn_launch_zero(ptr, n, stream); };
+    // a failed fill must not be followed by atomics into whatever the buffer held
+    int rc = 0;
+    auto zero = [&](float* ptr, size_t n) { if (!rc) rc = acattn_launch_zero(ptr, n, stream); };
     if (io.part_stride) {
       float* lo = std::min(io.dw_order_part, std::min(io.dw_dist_part, io.dsmall_part));
       zero(lo, rows * io.part_stride);
@@ -956,6 +960,7 @@ int launch_stream(const acattn_problem& p, const acattn_bwd_io& io, float* ws, h
       zero(io.dw_dist_part, rows * 2 * dh);
       zero(io.dsmall_part, rows * 4);
     }
+    if (rc) return rc;
   }
   const dim3 grid(p.B * p.n_heads * nT), block(64);
   hipLaunchKernelGGL((acattn_bwd_row_kernel<DH>), grid, block, 0, stream, p, io, ws);

@@ -274,7 +274,7 @@ __device__ __forceinline__ void store_out1(float* p, const float v) { __builtin_
 // Does some row of query block qb of sequence b carry a non-zero CONTEXT cotangent (d_ctx_*)?
 __device__ __forceinline__ bool qblock_has_ctx(const acattn_bwd_io& IO, int b, int qb) {
   if (IO.active_qblocks) return (IO.active_qblocks[b] >> qb) & 1u;
-  if (IO.read_rows) {
+  if (IO.read_rows) {  // (a position outside [0, L) matches no block: its row is treated as carrying no cotangent)
     for (int r = 0; r < IO.n_read_rows; ++r)
       if ((int)(IO.read_rows[(size_t)b * IO.n_read_rows + r] >> 4) == qb) return true;
     return false;

@@ -98,7 +98,11 @@ __device__ __forceinline__ Rows<NB> wave_rows(const acattn_tail_problem& P) {
     w.row[nb] = r < R ? r : R - 1;
     // gather and tail commute (the tail is position-wise): the positions the model reads are picked here instead of
     // by a gather launch per tensor in front of the tail (and a scatter launch per gradient behind it)
-    w.src[nb] = P.src_index ? (int64_t)(w.row[nb] / P.src_R) * P.src_L + P.src_index[w.row[nb]] : w.row[nb];
+    // (positions are clamped into [0, src_L): an out-of-range one -- item_seq_len == 0 gives -1 -- is a caller error that
+    // must not become an access outside the sequence)
+    w.src[nb] = P.src_index
+                    ? (int64_t)(w.row[nb] / P.src_R) * P.src_L + min(max((int)P.src_index[w.row[nb]], 0), P.src_L - 1)
+                    : w.row[nb];
   }
   return w;
 }

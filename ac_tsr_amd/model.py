@@ -38,8 +38,12 @@ def _cfg(config, key, default=None):
     return default if val is None else val
 
 
-def _penalty(attack_mask):
-    """torch.norm(1 - attack_mask, p=2) (acsasrec.py:135, acbert4rec.py:231)."""
+def _penalty(attack_mask, mode="local"):
+    """torch.norm(1 - attack_mask, p=2) (acsasrec.py:135, acbert4rec.py:231).  mode 'global' (config key
+    `dp_mask_penalty`): the norm over every data-parallel rank's batch (parallel.global_mask_penalty)."""
+    if mode == "global":
+        from .parallel import global_mask_penalty
+        return global_mask_penalty(attack_mask)
     if attack_mask.is_cuda and attack_mask.dtype == torch.float32:
         return mask_penalty(attack_mask)
     return torch.norm(1 - attack_mask, p=2)
@@ -126,6 +130,10 @@ class ACSASRec(SequentialRecommender):
         self.use_order = _cfg(config, 'use_order')
         self.use_distance = _cfg(config, 'use_distance')
         self.trainable_mask_loss_weight = _cfg(config, 'trainable_mask_loss_weight')
+        # not a reference key: how the mask penalty is taken under batch data-parallelism ('local': per-rank norm, the
+        # DDP convention; 'global': the norm one process on the concatenated batch would see -- parallel.py)
+        self.dp_mask_penalty = _cfg(config, 'dp_mask_penalty') or 'local'
+        assert self.dp_mask_penalty in ('local', 'global'), self.dp_mask_penalty
         # The reference never forwards seq_length (acsasrec.py:40-54), which pins the gate to L = 50
         # (layers.py:863,878).  `gate_seq_length` is an opt-in extension for other lengths.
         seq_length = _cfg(config, 'gate_seq_length', 50)
@@ -203,14 +211,14 @@ class ACSASRec(SequentialRecommender):
         final_attacked_loss = None
         if attacked_output is not None:
             if (self.loss_type == 'CE' and not self.trainable_mask_loss_weight and attacked_output.is_cuda
-                    and ce.supported(self.hidden_size) and torch.is_grad_enabled()):
+                    and ce.supported(self.hidden_size) and torch.is_grad_enabled() and self.dp_mask_penalty == 'local'):
                 # the whole expression below as one node (CE sweep with its direction, one finishing launch)
                 final_attacked_loss = ce.attacked_loss(attacked_output, self.item_embedding.weight,
                                                        interaction[self.POS_ITEM_ID], all_attack_masks,
                                                        self.mask_loss_weight, self.step_state)
         if attacked_output is not None and final_attacked_loss is None:
             attacked_loss = -self._cal_loss(attacked_output, interaction, attack_loss=True)
-            mask_penalty = [_penalty(m) for m in all_attack_masks if m is not None]
+            mask_penalty = [_penalty(m, self.dp_mask_penalty) for m in all_attack_masks if m is not None]
             assert len(mask_penalty) > 0
             mask_penalty = torch.mean(torch.stack(mask_penalty, dim=0))
             if self.trainable_mask_loss_weight:
@@ -271,6 +279,10 @@ class AcBERT4Rec(SequentialRecommender):
         self.use_order = _cfg(config, 'use_order')
         self.use_distance = _cfg(config, 'use_distance')
         self.trainable_mask_loss_weight = _cfg(config, 'trainable_mask_loss_weight')
+        # not a reference key: how the mask penalty is taken under batch data-parallelism ('local': per-rank norm, the
+        # DDP convention; 'global': the norm one process on the concatenated batch would see -- parallel.py)
+        self.dp_mask_penalty = _cfg(config, 'dp_mask_penalty') or 'local'
+        assert self.dp_mask_penalty in ('local', 'global'), self.dp_mask_penalty
         self.cloze_on_device = bool(_cfg(config, 'cloze_on_device', False))
         seq_length = _cfg(config, 'gate_seq_length', 50)
 
@@ -419,7 +431,7 @@ class AcBERT4Rec(SequentialRecommender):
         if self.loss_type == 'BPR':
             raise NotImplementedError("the reference computes only the CE loss here (acbert4rec.py:201-209)")
         attacked_loss = -self._cal_loss(attacked_seq_output, pos_items, targets, attack_loss=True)
-        mask_penalty = torch.mean(torch.stack([_penalty(m) for m in all_attack_masks], dim=0))
+        mask_penalty = torch.mean(torch.stack([_penalty(m, self.dp_mask_penalty) for m in all_attack_masks], dim=0))
         if self.trainable_mask_loss_weight:
             final_attacked_loss = attacked_loss + mask_penalty * self.mask_loss_weight[0]
         else:

@@ -5,7 +5,9 @@ part of the training step bench.py measures.  `Adam` below IS torch.optim.Adam -
 (`step`, `exp_avg`, `exp_avg_sq` per parameter, `capturable`: the step counters live on the device), same state_dict --
 with `step()` routed to the library when the situation is the plain one (fp32 parameters and dense gradients on one HIP
 device, no amsgrad / maximize / differentiable, float learning rate).  Anything else, and the very first step (which
-creates the state), goes through torch's own implementation.  The arithmetic reproduces ATen's fused kernel operation by
+creates the state), goes through torch's own implementation.  The learning rate travels to the launch BY VALUE: a
+captured graph replays the rate of the capture (trainer.enable_graph refuses a model whose optimizer has an LR scheduler
+attached; use a tensor `lr`, which takes torch's path, to change it under replay).  The arithmetic reproduces ATen's fused kernel operation by
 operation (csrc/acattn_adam.hip; tests/test_hip_adam.py compares the two).
 """
 from __future__ import annotations
@@ -34,7 +36,11 @@ class Adam(torch.optim.Adam):
                 and len(self.state[p]) != 0 and torch.is_tensor(self.state[p]["step"]) and self.state[p]["step"].is_cuda
                 and self.state[p]["step"].dtype == torch.float32 for p in ps)
             if not ok or not ps:
-                return super().step(closure)
+                # torch's own implementation, UNDECORATED: both this step() and torch.optim.Adam.step are wrapped by
+                # Optimizer.profile_hook_step, and going through the wrapper again would run the step pre / post hooks
+                # (and an LR scheduler's step counting) twice
+                inner = getattr(torch.optim.Adam.step, "__wrapped__", None)
+                return inner(self, closure) if inner is not None else super().step(closure)
             todo.append((group, ps))
         loss = None
         if closure is not None:

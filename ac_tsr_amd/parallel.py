@@ -14,12 +14,20 @@ gradient when pass 1 (calibrated loss) ends: pass 2 only reaches the attack tran
 included: 99.9 % of the bytes) right after pass 1, on the communication stream, and pass 2 runs under
 it; `all_reduce()` after pass 2 sends the attack transforms' 66 KB and waits for both.
 
-Not identical to one process on the global batch in ONE term: the attacked loss carries
+Not identical to one process on the global batch in ONE term, by default: the attacked loss carries
 `torch.norm(1 - M)` over the whole (local) batch (acsasrec.py:131-137), and a norm is not additive.
 Averaging per-rank gradients weights the mask penalty of the attack transforms by 1/sqrt(N) relative
 to a single process seeing all N shards (the cross-entropy terms are exact means).  This is the
 DDP-conventional "per-rank penalty" (SURVEY.md section 8e); every other gradient equals the
-single-process one.
+single-process one.  The exact alternative is `global_mask_penalty` below (model config key
+`dp_mask_penalty: 'global'`): the per-layer sums of squares are all-reduced before the square root -- one
+scalar per layer -- and N ranks then take exactly the step of one process on the concatenated batch.
+
+Collective form.  `collective="all_reduce"` (default) is one all-reduce per bucket; `"reduce_scatter"`
+is a reduce-scatter followed by an all-gather of the same bucket.  On MI355X's fully connected xGMI
+(7 links per GPU) a ring all-reduce is bound by ONE link, while a reduce-scatter / all-gather pair
+addresses all 7 peers at once; which one RCCL's own all-reduce picks is its
+business, the flag makes the choice explicit and measurable (bench.py --dp-collective).
 
 Works with backend "gloo" on CPU tensors as well (world_size-2 tests run without a GPU).
 """
@@ -72,10 +80,12 @@ class GradSynchronizer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20, group=None,
-                 accumulate_in_place: bool = False, late: Iterable[torch.nn.Parameter] = ()):
+                 accumulate_in_place: bool = False, late: Iterable[torch.nn.Parameter] = (),
+                 collective: str = "all_reduce"):
         """`late`: the parameters whose gradient is only complete after the LAST backward pass (the attack transforms
         under the two-pass trainer).  They sit at the end of the flat buffer; everything in front of them can be
-        reduced early (`reduce_early`)."""
+        reduced early (`reduce_early`).  `collective`: "all_reduce" or "reduce_scatter" (+ all-gather), see above."""
+        assert collective in ("all_reduce", "reduce_scatter"), collective
         late_ids = {id(p) for p in late}
         every = [p for p in params]
         self.params: List[torch.nn.Parameter] = [p for p in every if id(p) not in late_ids] + \
@@ -83,26 +93,34 @@ class GradSynchronizer:
         self.n_early = sum(1 for p in every if id(p) not in late_ids) if late_ids else 0
         assert self.params, "no parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
-        total = sum(p.numel() for p in self.params)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = collective
+        # the early and the late section are each padded to a multiple of the world size: a reduce-scatter hands every
+        # rank an equal share of a bucket (a few zeros at most; an all-reduce does not care)
+        pad = lambda n: -(-n // self.world) * self.world
+        early_raw = sum(p.numel() for p in self.params[:self.n_early])
+        late_raw = sum(p.numel() for p in self.params[self.n_early:])
+        self.early_numel = pad(early_raw)
+        total = self.early_numel + pad(late_raw)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
         self.views: List[torch.Tensor] = []
         off = 0
-        for p in self.params:
+        for k, p in enumerate(self.params):
+            if k == self.n_early:
+                off = self.early_numel
             n = p.numel()
             self.views.append(self.flat[off:off + n].view_as(p))
             off += n
         self.in_place = accumulate_in_place
         if self.in_place:
             self.attach()
-        per = max(1, bucket_bytes // self.flat.element_size())
+        per = pad(max(1, bucket_bytes // self.flat.element_size()))
         # buckets never straddle the early / late boundary
-        self.early_numel = sum(p.numel() for p in self.params[:self.n_early])
         self.early_buckets = [self.flat[s:min(s + per, self.early_numel)] for s in range(0, self.early_numel, per)]
         self.late_buckets = [self.flat[s:min(s + per, total)] for s in range(self.early_numel, total, per)]
         self.buckets = self.early_buckets + self.late_buckets
         self._early_works = None
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
 
     @classmethod
@@ -143,7 +161,17 @@ class GradSynchronizer:
 
     def _start(self, buckets):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        return [dist.all_reduce(b, op=op, group=self.group, async_op=True) for b in buckets]
+        if self.collective == "all_reduce":
+            return [dist.all_reduce(b, op=op, group=self.group, async_op=True) for b in buckets]
+        # reduce-scatter into this rank's share of the bucket (in place), then all-gather the shares back
+        works = []
+        rank = dist.get_rank(self.group)
+        for b in buckets:
+            n = b.numel() // self.world
+            mine = b[rank * n:(rank + 1) * n]
+            works.append(_reduce_scatter(mine, b, op, self.group, self.world, rank))
+            works.append(dist.all_gather_into_tensor(b, mine, group=self.group, async_op=True))
+        return works
 
     def reduce_early(self, packed: bool = False) -> None:
         """Call between the backward passes: starts the all-reduce of every gradient that is already final (all but
@@ -172,6 +200,51 @@ class GradSynchronizer:
             w.wait()
         if self.world > 1 and not self._avg:
             self.flat.div_(self.world)
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _reduce_scatter(out: torch.Tensor, whole: torch.Tensor, op, group, world: int, rank: int):
+    """reduce_scatter_tensor where the backend has it (RCCL); over gloo, which has not, one reduce per share rooted at
+    the share's owner -- the same result, used by the CPU tests."""
+    if dist.get_backend(group) != "gloo":
+        return dist.reduce_scatter_tensor(out, whole, op=op, group=group, async_op=True)
+    n = whole.numel() // world
+    for r in range(world):
+        dist.reduce(whole[r * n:(r + 1) * n], dst=dist.get_global_rank(group, r) if group is not None else r, op=op, group=group)
+    return _Done()
+
+
+class _GlobalNorm(torch.autograd.Function):
+    """|| 1 - M ||_2 over the GLOBAL batch (torch.norm(1 - attack_mask, p=2), acsasrec.py:135, with M the
+    concatenation of every rank's mask): sum of squares locally, all-reduce of that scalar, square root.  Backward:
+    d M = d * world * (M - 1) / norm -- the factor `world` because the synchronizer AVERAGES the ranks' gradients,
+    and the single process' gradient is their SUM for this term (its shards' contributions add up under one root)."""
+
+    @staticmethod
+    def forward(ctx, m, group):
+        s = ((1.0 - m) ** 2).sum()
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+        norm = s.sqrt()
+        ctx.save_for_backward(m, norm)
+        ctx.world = dist.get_world_size(group)
+        return norm
+
+    @staticmethod
+    def backward(ctx, d):
+        m, norm = ctx.saved_tensors
+        return d * ctx.world * (m - 1.0) / norm, None
+
+
+def global_mask_penalty(attack_mask: torch.Tensor, group=None) -> torch.Tensor:
+    """The mask penalty of one layer as ONE process on the concatenated batch would compute it; a plain local norm
+    when no process group is up (or it has one member)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return torch.norm(1 - attack_mask, p=2)
+    return _GlobalNorm.apply(attack_mask, group)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:

@@ -18,11 +18,13 @@ import torch
 
 
 import os as _os
+_CONFLICT = object()  # StepState.table_grad: two nodes published in one pass
 _NO_HANDOVER = _os.environ.get("ACATTN_NO_HANDOVER") == "1"  # measurement / bisection hook
 
 
 class StepState:
-    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "grad_home", "_frozen")
+    __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "grad_home", "_frozen",
+                 "_home_claimed")
 
     def __init__(self, frozen: bool = False):
         object.__setattr__(self, "_frozen", False)
@@ -39,8 +41,16 @@ class StepState:
         # scatter target).  Instead the cross-entropy node PUBLISHES its gradient tensor here and the embedding node,
         # which autograd runs later (it is upstream), scatters straight into it and returns nothing for the table.
         # `tick` orders forwards: the embedding node only takes a gradient published by a loss node built after it.
+        # The hand-over is only sound when ONE node produces a table gradient in the walk: with two, autograd sums their
+        # tensors as soon as the second arrives and nobody reads the published one any more -- the scattered rows would
+        # be lost.  One producer is what the trainer's pass 1 guarantees (calibrated_loss.backward(inputs=...) walks one
+        # loss: recbole/trainer/trainer.py:672-677), so nodes publish only inside `calibrated_pass()`, a second
+        # publication in the same pass withdraws the first (the embedding node then returns its own gradient and
+        # autograd adds), and any other walk -- sum(losses).backward(), torch.autograd.grad on a user loss -- takes the
+        # plain path.
         self.tick: int = 0
-        self.table_grad = None  # (tick of the publishing node's forward, the table, its gradient tensor)
+        self.table_grad = None  # (tick of the publishing node's forward, the table, its gradient tensor) | _CONFLICT
+        self._home_claimed = None  # data_ptrs whose flat-buffer home was handed out in this pass (see grad_buffer_for)
         # Data parallelism keeps every gradient in one flat buffer (parallel.GradSynchronizer).  A node that produces a
         # parameter's WHOLE gradient in one launch (the cross-entropy's dense table gradient: 99.9 % of the model's
         # bytes) can write it there directly instead of into a fresh tensor that is copied over afterwards:
@@ -49,9 +59,27 @@ class StepState:
         object.__setattr__(self, "_frozen", frozen)
 
     def __setattr__(self, name, value):
-        if self._frozen:
+        if getattr(self, "_frozen", False):  # (unpickling / copy.copy restore the slots before `_frozen` exists)
             raise AttributeError("state.DEFAULT is read-only: attach a StepState to the model (StepState().attach(model))")
         object.__setattr__(self, name, value)
+
+    def __getstate__(self):
+        # what survives pickling (torch.save(model), mp.spawn): the settings, not the per-walk hand-over state nor the
+        # views into a synchronizer's flat buffer
+        return {"pass_mode": self.pass_mode, "prune_dead_work": self.prune_dead_work, "seed_salt": self.seed_salt,
+                "seed_tensor": self.seed_tensor, "tick": self.tick, "frozen": self._frozen}
+
+    def __setstate__(self, st):
+        object.__setattr__(self, "_frozen", False)
+        self.pass_mode, self.prune_dead_work, self.seed_salt = st["pass_mode"], st["prune_dead_work"], st["seed_salt"]
+        self.seed_tensor, self.tick = st["seed_tensor"], st["tick"]
+        self.table_grad = self.grad_home = self._home_claimed = None
+        object.__setattr__(self, "_frozen", st["frozen"])
+
+    def __copy__(self):
+        new = StepState()
+        new.__setstate__(self.__getstate__())
+        return new
 
     def __deepcopy__(self, memo):
         new = StepState()
@@ -75,6 +103,8 @@ class StepState:
     def _pass(self, mode):
         prev = self.pass_mode
         self.pass_mode = mode
+        self.table_grad = None  # a new walk: nothing published, no flat-buffer home handed out yet
+        self._home_claimed = None
         try:
             yield self
         finally:
@@ -96,12 +126,16 @@ class StepState:
         return self.tick
 
     def publish_table_grad(self, tick: int, table: torch.Tensor, grad: Optional[torch.Tensor]) -> None:
-        if not self._frozen and tick >= 0 and grad is not None:
-            self.table_grad = (tick, table, grad)
+        if self._frozen or tick < 0 or grad is None or self.pass_mode != "calibrated":
+            return
+        self.table_grad = (tick, table, grad) if self.table_grad is None else _CONFLICT
 
     def take_table_grad(self, tick: int, table: torch.Tensor) -> Optional[torch.Tensor]:
-        """The gradient tensor a loss node downstream of the caller published for `table` in this backward walk."""
+        """The gradient tensor THE loss node downstream of the caller published for `table` in this backward walk."""
         if self._frozen or self.table_grad is None or tick < 0 or _NO_HANDOVER:
+            return None
+        if self.table_grad is _CONFLICT:
+            self.table_grad = None
             return None
         t, tab, grad = self.table_grad
         if t > tick and tab.data_ptr() == table.data_ptr() and grad.shape == table.shape:
@@ -112,8 +146,15 @@ class StepState:
     def grad_buffer_for(self, param: torch.Tensor) -> Optional[torch.Tensor]:
         """The flat-buffer view a full gradient of `param` may be written into, or None (no synchronizer, or the parameter
         already holds a gradient that autograd would ADD this one to)."""
-        if self._frozen or not self.grad_home or param.grad is not None:
+        if self._frozen or not self.grad_home or param.grad is not None or self.pass_mode != "calibrated":
             return None
+        # once per pass and parameter: a second producer of the same walk would overwrite the first one's bytes (both see
+        # param.grad is None until the walk ends)
+        claimed = self._home_claimed if self._home_claimed is not None else set()
+        if param.data_ptr() in claimed:
+            return None
+        claimed.add(param.data_ptr())
+        self._home_claimed = claimed
         home = self.grad_home.get(param.data_ptr())
         # a fresh tensor object on the same memory: autograd keeps a gradient without copying it only if nobody else
         # holds the tensor object (AccumulateGrad's use_count test), and the synchronizer holds `home`

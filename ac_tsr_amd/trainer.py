@@ -122,14 +122,14 @@ class AttackSASRecTrainer:
 
     _seed_t = None
 
-    def enable_graph(self, example_interaction, warmup: int = 3):
+    def enable_graph(self, example_interaction, warmup: int = 3, debug_dump: Optional[str] = None):
         """Capture the training step into hipGraphs (about 350 short kernels per step: eager launches are host-bound).
         Inputs are copied into static buffers before each replay; the in-kernel RNG adds a device-side step counter to
         its seeds so every replay draws fresh noise / dropout.  Without a gradient synchronizer the whole step incl.
         the optimizer is ONE graph.  With one, the step is TWO graphs sharing a memory pool -- forward + pass 1 +
         packing of the early gradients, then pass 2 + packing of the attack transforms' -- and the collectives and
         the optimizer step are issued eagerly: the early all-reduce between the two replays (it overlaps pass 2), the
-        rest after."""
+        rest after.  `debug_dump`: path of a .dot file that receives the captured graph (hipGraphDebugDotPrint)."""
         assert self.device.type == 'cuda'
         assert warmup >= 1, "at least one eager step must precede the capture (it creates the optimizer's state)"
         for m in self.model.modules():
@@ -138,6 +138,13 @@ class AttackSASRecTrainer:
             if getattr(m, 'combine_option', None) == 'annealing':
                 raise ValueError("combine_option='annealing' cannot run from a captured graph: the anneal rate is "
                                  "recomputed on the host for every forward (layers.py:890-891); train it eagerly")
+        if any(isinstance(g.get('lr'), float) and g.get('initial_lr') is not None for g in self.optimizer.param_groups):
+            # an LR scheduler registers `initial_lr` in every group; the float rate is frozen into the captured launch
+            raise ValueError("an LR scheduler is attached to the optimizer: a captured step replays the learning rate of "
+                             "the capture (ac_tsr_amd/optim.py); train eagerly or give the optimizer a tensor lr")
+        if getattr(self.model, 'dp_mask_penalty', 'local') == 'global' and self.grad_sync is not None and self.grad_sync.world > 1:
+            raise ValueError("dp_mask_penalty='global' all-reduces a scalar per layer INSIDE the forward (parallel.py); "
+                             "that collective is not captured here: train it eagerly")
         self._static_in = {k: v.clone() for k, v in example_interaction.items()}
         self._seed_t = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.state.seed_tensor = self._seed_t
@@ -149,7 +156,9 @@ class AttackSASRecTrainer:
                 self._eager_step(self._static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if debug_dump else torch.cuda.CUDAGraph()
+        if debug_dump:
+            graph.enable_debug_mode()  # keeps the captured hipGraph so that debug_dump can print it (diagnosis only)
         self._graph2 = None
         if self.grad_sync is None:
             with torch.cuda.graph(graph):
@@ -171,6 +180,9 @@ class AttackSASRecTrainer:
                     self._pass_two(outs[0])
                     self.grad_sync.pack("all")
             self.grad_sync.attach()  # from now on .grad are the flat views the captured pack() fills on every replay
+        if debug_dump:
+            self._raw_graph = graph.raw_cuda_graph() if hasattr(graph, "raw_cuda_graph") else None  # hipGraph_t (diagnosis)
+            graph.debug_dump(debug_dump)  # hipGraphDebugDotPrint: nodes and dependency edges as a .dot file
         self._graph, self._static_out = graph, outs
         return self
 

@@ -47,8 +47,12 @@ def parse():
     ap.add_argument("--inner", type=int, default=256)
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short measurements of the other named shapes (L=200 d=64, configs[3], configs[4])")
     ap.add_argument("--kernel-only", action="store_true", help="only the kernel roofline measurement")
     ap.add_argument("--kernel-iters", type=int, default=300)
+    ap.add_argument("--kernel-kinds", default="ragged,full,spatial",
+                    help="--kernel-only: which forward-kernel measurements to run (counter passes want one at a time)")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-full-schedule", action="store_true",
@@ -61,6 +65,9 @@ def parse():
                     help="layer tail: the fused launch (acattn_layer_tail_*) or the unfused node; measurements only")
     ap.add_argument("--projections", choices=["fused", "library"], default="fused",
                     help="the six projections of a layer: one launch (acattn_projections_*) or hipBLASLt GEMMs; measurements only")
+    ap.add_argument("--dp-collective", choices=["all_reduce", "reduce_scatter"], default="all_reduce",
+                    help="gradient exchange under data parallelism: one all-reduce per bucket, or reduce-scatter + "
+                         "all-gather (parallel.GradSynchronizer)")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffer, graph without optimizer) even on one GPU")
     a = ap.parse_args()
@@ -182,13 +189,13 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None, full_len
     alg = ops.fwd_algorithmic_bytes(B, L, H, nh, adversarial, "gate")
     achieved = alg / (best * 1e-6) / 1e9
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "fwd_pmc_latest.json")
-    if os.path.exists(pmc) and (B, L, H, nh) == (512, 50, 64, 2) and not full_length:
+    pmc = os.path.join(ROOT, "profiles", "r03_fwd_pmc_full_length.json" if full_length else "fwd_pmc_latest.json")
+    if os.path.exists(pmc) and (B, L, H, nh) == (512, 50, 64, 2):
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and shape
         # (FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 FETCH_SIZE x2 correction applied)
         k = json.load(open(pmc))["kernels"].get(kernel_name)
         if k and "hbm_bytes_per_launch_corrected" in k:
-            traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/fwd_pmc_latest.json"
+            traffic, traffic_src = k["hbm_bytes_per_launch_corrected"], "profiles/" + os.path.basename(pmc)
 
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -196,6 +203,69 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None, full_len
             "contract": "A" if adversarial else "A'", "algorithmic_bytes_per_launch": alg,
             "item_length": "all L" if full_length else "U{1..L}",
             "avg_launch_us": round(best, 2), "launches_timed": 3 * iters, "buffer_sets": nsets}
+
+
+# --------------------------------------------------------------------------------------------------
+# the other shapes north_star / BASELINE.json name, a handful of steps each, appended to the default line
+# --------------------------------------------------------------------------------------------------
+OTHER_CONFIGS = [
+    # (label, overrides)
+    ("north_star second shape: AC-SASRec B=512 L=200 d=64 2 heads", dict(seq_len=200)),
+    ("BASELINE configs[3]: AC-SASRec B=512 L=200 d=128 4 heads", dict(seq_len=200, hidden=128, heads=4, inner=512)),
+    ("BASELINE configs[4]: AC-BERT4Rec (bidirectional mask) B=512 L=200 d=256 4 heads, 20000 items",
+     dict(seq_len=200, hidden=256, heads=4, inner=1024, items=20000, model="AcBERT4Rec")),
+]
+
+
+def other_configs(a, device, steps=8, warmup=3):
+    """ms/step, sequences/s and the forward kernel's roofline fraction of the other named shapes (one GPU, hipGraph replay,
+    same synthetic data recipe).  Short on purpose: the default run must stay within a couple of minutes."""
+    import copy
+    import gc
+    import ac_tsr_amd as A
+    out = []
+    for label, over in OTHER_CONFIGS:
+        b = copy.copy(a)
+        for k, v in over.items():
+            setattr(b, k, v)
+        torch.manual_seed(42)
+        rec = {"workload": label}
+        model = trainer = pool = None
+        try:
+            model = getattr(A, b.model)(A.DictConfig(model_config(b)), A.ItemCount(b.items)).to(device)
+            if b.model == "AcBERT4Rec":
+                model.cloze_on_device = True
+            trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model)
+            model.train()
+            gen = torch.Generator().manual_seed(2000)
+            pool = [synthetic_batch(b.batch, b.seq_len, b.items, gen, device) for _ in range(2)]
+            trainer.enable_graph(pool[0])
+            for i in range(warmup):
+                trainer.train_step(pool[i % 2])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            last = None
+            for i in range(steps):
+                last = trainer.train_step(pool[i % 2])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            losses = [float(x.detach()) for x in last]
+            rec.update(ms_per_step=round(dt * 1e3, 3), value=round(b.batch / dt, 1), unit="user-sequences/sec", steps=steps,
+                       final_losses=[round(x, 4) for x in losses], finite=all(x == x for x in losses))
+        except Exception as e:  # a shape that does not run must show up in the line, not end the run
+            rec["error"] = f"{type(e).__name__}: {e}"[:300]
+        del trainer, model, pool
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            r = kernel_roofline(b, device, True, iters=20, nsets=1)
+            rec["roofline"] = {k: r[k] for k in ("frac", "achieved", "avg_launch_us", "kernel", "algorithmic_bytes_per_launch")}
+        except Exception as e:
+            rec["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        gc.collect()
+        torch.cuda.empty_cache()
+        out.append(rec)
+    return out
 
 
 # --------------------------------------------------------------------------------------------------
@@ -249,6 +319,10 @@ def cpu_baseline(a, state_dict, steps):
 
 
 def main():
+    # a process that dies in native code (a fault at teardown, an abort inside a library) leaves its Python stack on
+    # stderr; together with the exit marker at the very end this turns "empty stdout" into a record of where it ended
+    import faulthandler
+    faulthandler.enable(file=sys.stderr, all_threads=True)
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -257,9 +331,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     # A process that starts while the previous GPU process of the same box is still being torn down has (rarely: 2 of
     # ~40 back-to-back launches) found no device; wait for the device before doing anything, then fail loudly.
-    for _ in range(10):
+    for attempt in range(10):
         if torch.cuda.is_available():
             break
+        # never silent: if this ever happens again the record says when and how long
+        print(f"bench.py: no HIP device visible yet (attempt {attempt + 1}/10, pid {os.getpid()}, t={time.time():.3f})",
+              file=sys.stderr, flush=True)
         time.sleep(1.0)
     else:
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -291,9 +368,14 @@ def main():
     import torch.distributed as dist
 
     if a.kernel_only:
-        out = {"roofline": kernel_roofline(a, device, True, a.kernel_iters),
-               "roofline_full_length": kernel_roofline(a, device, True, a.kernel_iters, full_length=True),
-               "roofline_spatial_only": kernel_roofline(a, device, False, a.kernel_iters)}
+        kinds = a.kernel_kinds.split(",")
+        out = {}
+        if "ragged" in kinds:
+            out["roofline"] = kernel_roofline(a, device, True, a.kernel_iters)
+        if "full" in kinds:
+            out["roofline_full_length"] = kernel_roofline(a, device, True, a.kernel_iters, full_length=True)
+        if "spatial" in kinds:
+            out["roofline_spatial_only"] = kernel_roofline(a, device, False, a.kernel_iters)
         print(json.dumps(out), flush=True)
         return
 
@@ -302,7 +384,7 @@ def main():
     if a.model == "AcBERT4Rec":
         model.cloze_on_device = True  # the cloze batch is built with tensor ops: the whole step replays as a graph
     parallel.broadcast_parameters(model)
-    sync = parallel.GradSynchronizer.for_two_pass_model(model) if (world > 1 or a.force_grad_sync) else None
+    sync = parallel.GradSynchronizer.for_two_pass_model(model, collective=a.dp_collective) if (world > 1 or a.force_grad_sync) else None
     trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model, grad_sync=sync)
     model.train()
     gen = torch.Generator().manual_seed(1000 + rank)
@@ -387,6 +469,8 @@ def main():
         # algorithmic bytes are the same, no key tile past the last item can be skipped
         res["roofline_full_length"] = kernel_roofline(a, device, True, a.kernel_iters, full_length=True)
         res["roofline_spatial_only"] = kernel_roofline(a, device, False, a.kernel_iters)
+        if world == 1 and a.config is None and not a.no_other_configs and (a.batch, a.seq_len, a.hidden, a.heads) == (512, 50, 64, 2):
+            res["other_configs"] = other_configs(a, device)
         if world == 1 and not a.no_cpu_baseline and a.model == "ACSASRec":
             res["cpu_baseline"] = cpu_baseline(a, init_state, a.cpu_steps)
         else:
@@ -407,6 +491,8 @@ def main():
     import gc
     gc.collect()
     torch.cuda.synchronize()
+    # last action of the process' own code: everything after this line on stderr is interpreter / runtime teardown
+    print(f"bench.py: exit marker rank={rank} pid={os.getpid()} status=ok", file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":

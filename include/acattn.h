@@ -151,7 +151,9 @@ typedef struct acattn_bwd_io {
                            (acattn_bwd_stream.hip); NULL = the row-resident kernels only. */
   const int64_t* read_rows; /* the same hint as active_qblocks in its raw form: [B, n_read_rows] positions whose context
                            cotangents are the only non-zero ones (item_seq_len - 1 of abstract_recommender.py:130-134).
-                           Consulted when active_qblocks is NULL; NULL = all active. */
+                           Consulted when active_qblocks is NULL; NULL = all active.  PRECONDITION: 0 <= position < L
+                           (the reference's gather raises an index error otherwise); the kernels clamp a position
+                           outside that range into it rather than touch another sequence's memory. */
   int32_t n_read_rows;
 } acattn_bwd_io;
 

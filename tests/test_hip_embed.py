@@ -83,19 +83,22 @@ def test_counter_dropout_statistics_eval_identity_and_bad_ids():
 
 
 def test_table_gradient_hand_over_equals_autograd_sum():
-    """The item table is both the embedding table and the CE classifier (acsasrec.py:87, 117-120).  With a StepState the
-    cross-entropy node publishes its dense table gradient and the embedding backward scatters into it
-    (StepState.table_grad); without one autograd adds the two.  Same gradients either way, also over two walks, and
-    nothing is handed over to a lookup of another table or across walks."""
+    """The item table is both the embedding table and the CE classifier (acsasrec.py:87, 117-120).  Inside the
+    trainer's calibrated pass (ONE loss walked: recbole/trainer/trainer.py:672-677) the cross-entropy node publishes its
+    dense table gradient and the embedding backward scatters into it (StepState.table_grad); anywhere else, and as
+    soon as TWO nodes produce a table gradient in one walk, autograd adds the tensors.  Same gradients every way, also
+    over two walks; nothing is handed over to a lookup of another table or across walks."""
+    import contextlib
     from ac_tsr_amd import ce
     from ac_tsr_amd.state import StepState
     B, L, H, N = 16, 12, 64, 300
     g = torch.Generator().manual_seed(3)
     idx = torch.randint(0, N, (B, L), generator=g).to(DEV)
     target = torch.randint(1, N, (B,), generator=g).to(DEV)
+    target2 = torch.randint(1, N, (B,), generator=g).to(DEV)
     cot = torch.randn(B, L, H, generator=g).to(DEV)
 
-    def grads(state):
+    def grads(state, in_pass=False, two_losses=False):
         torch.manual_seed(0)
         emb = torch.nn.Embedding(N, H, padding_idx=0).to(DEV)
         pos = torch.nn.Embedding(L, H).to(DEV)
@@ -103,21 +106,75 @@ def test_table_gradient_hand_over_equals_autograd_sum():
         if state is not None:
             for m in (emb, pos, norm):
                 state.attach(m)
+        kw = {} if state is None else {"state": state}
         out = []
         for _ in range(2):  # two forward/backward walks: nothing stale survives the first
             emb.weight.grad = None
             y = fused_embed.embed_layer_norm(idx, emb, pos, norm, 0.0, training=True)
-            loss = ce.full_sort_cross_entropy(y[:, -1, :], emb.weight, target, **({} if state is None else {"state": state}))
-            (loss + (y * cot).sum() * 1e-2).backward()
+            loss = ce.full_sort_cross_entropy(y[:, -1, :], emb.weight, target, **kw)
+            if two_losses:  # a second producer of a table gradient in the same walk (sum(losses).backward())
+                loss = loss + 0.5 * ce.full_sort_cross_entropy(y[:, 0, :], emb.weight, target2, **kw)
+            with (state.calibrated_pass() if in_pass else contextlib.nullcontext()):
+                (loss + (y * cot).sum() * 1e-2).backward()
             out.append(emb.weight.grad.clone())
         return out
 
+    close = lambda a, b: (a - b).abs().max() <= 1e-6 * a.abs().max() + 1e-9
     st = StepState()
-    ref, got = grads(None), grads(st)
-    assert st.tick == 4 and st.table_grad is None  # published twice, taken twice
-    for a, b in zip(ref, got):
-        assert (a - b).abs().max() <= 1e-6 * a.abs().max() + 1e-9
+    ref, got = grads(None), grads(st, in_pass=True)
+    assert st.table_grad is None  # published twice, taken twice
+    assert all(close(a, b) for a, b in zip(ref, got))
+    assert all(close(a, b) for a, b in zip(ref, grads(StepState())))  # no pass: the plain path
+    # two producers: the hand-over is withdrawn, inside the pass and outside it
+    ref2 = grads(None, two_losses=True)
+    for in_pass in (True, False):
+        st2 = StepState()
+        assert all(close(a, b) for a, b in zip(ref2, grads(st2, in_pass=in_pass, two_losses=True))), in_pass
+        assert st2.table_grad is None
     # a gradient published for ANOTHER table is left alone
     other = torch.nn.Embedding(N, H, padding_idx=0).to(DEV)
-    st.publish_table_grad(10 ** 9, other.weight, torch.zeros_like(other.weight))
-    assert grads(st)[0].sub(ref[0]).abs().max() <= 1e-6 * ref[0].abs().max() + 1e-9
+    with st.calibrated_pass():
+        st.publish_table_grad(10 ** 9, other.weight, torch.zeros_like(other.weight))
+    assert close(ref[0], grads(st, in_pass=True)[0])
+
+
+def test_sum_of_both_losses_backward_equals_the_two_pass_gradients():
+    """ACSASRec, `(attacked + calibrated).backward()` in ONE walk -- what RecBole's base Trainer does with a tuple of
+    losses (recbole/trainer/trainer.py:184-185) -- against the sum of the two separate walks with the hand-over switched
+    off: every parameter, the item table's lookup rows in particular."""
+    import ac_tsr_amd as A
+    from ac_tsr_amd import state as state_mod
+    torch.manual_seed(1)
+    cfg = dict(n_layers=2, n_heads=2, hidden_size=64, inner_size=256, hidden_dropout_prob=0.0, attn_dropout_prob=0.0,
+               hidden_act="gelu", layer_norm_eps=1e-12, initializer_range=0.02, loss_type="CE", combine_option="gate",
+               two_level=True, use_order=True, use_distance=True, rich_calibrated_combine="none", mask_loss_weight=0.03)
+    model = A.ACSASRec(A.DictConfig(cfg), A.ItemCount(500)).to(DEV).eval()  # eval: no dropout draws; the noise seed is pinned
+    B, L = 32, 50
+    g = torch.Generator().manual_seed(2)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.randint(1, 500, (B, L), generator=g) * (torch.arange(L)[None, :] < lens[:, None])
+    batch = {"item_id_list": ids.to(DEV), "item_length": lens.to(DEV), "item_id": torch.randint(1, 500, (B,), generator=g).to(DEV)}
+
+    def run(one_walk):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(7)
+        att, cal = model.calculate_loss(batch)
+        if one_walk:
+            (att + cal).backward()
+        else:
+            cal.backward(retain_graph=True)
+            att.backward()
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    old = state_mod._NO_HANDOVER
+    state_mod._NO_HANDOVER = True
+    try:
+        want = run(False)
+    finally:
+        state_mod._NO_HANDOVER = old
+    got = run(True)
+    assert set(got) == set(want)
+    for n in want:
+        # (float atomics land in a different order from walk to walk: ~2e-4 of a gradient's scale; rows lost to a broken
+        # hand-over would be off by the scale itself)
+        assert (got[n] - want[n]).abs().max().item() <= 2e-3 * want[n].abs().max().item() + 1e-8, n

@@ -230,3 +230,89 @@ def test_two_pass_trainer_with_synchronizer_on_two_ranks(tmp_path):
         assert torch.equal(s0[k], s1[k]), k
         assert (s0[k] - ref[k]).abs().max() <= 1e-5, k
 
+
+
+class _PenaltyToy(_TwoPassToy):
+    """_TwoPassToy whose attacked loss also carries the mask penalty of the models: a 2-norm over a tensor with one
+    slice per sequence of the batch (torch.norm(1 - attack_mask), acsasrec.py:131-137) -- the one term of the step that
+    is not a mean over sequences."""
+    penalty = "local"
+
+    def calculate_loss(self, batch):
+        x, y = batch
+        h = torch.tanh(self.body(self.item_embedding(x).mean(1)))
+        a = self.attack_query_transform(h) * torch.sigmoid(self.attack_key_transform(h))
+        m = torch.softmax(a, dim=-1)  # an "attack mask" [B, 8]
+        logits = (h + 0.1 * a) @ self.item_embedding.weight.t()
+        calibrated = torch.nn.functional.cross_entropy(logits, y)
+        attacked = -torch.nn.functional.cross_entropy((h + a) @ self.item_embedding.weight.t(), y)
+        pen = parallel.global_mask_penalty(m) if self.penalty == "global" else torch.norm(1 - m, p=2)
+        return attacked + 0.3 * pen, calibrated
+
+
+def _penalty_worker(rank, world, port, out, penalty, collective):
+    import ac_tsr_amd as A
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed("gloo")
+    model = _PenaltyToy()
+    model.penalty = penalty
+    parallel.broadcast_parameters(model, src=0)
+    sync = parallel.GradSynchronizer.for_two_pass_model(model, bucket_bytes=512, collective=collective)
+    assert sync.flat.numel() % world == 0 and all(b.numel() % world == 0 for b in sync.buckets)
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner="adam", learning_rate=1e-2), model, grad_sync=sync)
+    x, y = _toy_batch()
+    sl = parallel.shard_batch(x.shape[0], rank, world)
+    for _ in range(3):
+        trainer.train_step((x[sl], y[sl]))
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out, f"pen_{penalty}_{collective}_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("collective", ["all_reduce", "reduce_scatter"])
+def test_global_mask_penalty_makes_two_ranks_equal_one_process(tmp_path, collective):
+    """The mask penalty is a norm over the WHOLE batch (acsasrec.py:131-137).  With the per-layer sum of squares
+    all-reduced before the square root (parallel.global_mask_penalty, config `dp_mask_penalty: 'global'`) two ranks on
+    half the batch each take exactly the step of one process on the concatenated batch; with the per-rank norm (the
+    default) they do not -- and the reduce-scatter + all-gather form of the exchange moves the same numbers."""
+    import ac_tsr_amd as A
+    model = _PenaltyToy()
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner="adam", learning_rate=1e-2), model)
+    for _ in range(3):
+        trainer.train_step(_toy_batch())
+    ref = model.state_dict()
+    diffs = {}
+    for penalty in ("global", "local"):
+        port = _free_port()
+        mp.spawn(_penalty_worker, args=(2, port, str(tmp_path), penalty, collective), nprocs=2, join=True)
+        s0 = torch.load(tmp_path / f"pen_{penalty}_{collective}_rank0.pt")
+        s1 = torch.load(tmp_path / f"pen_{penalty}_{collective}_rank1.pt")
+        for k in ref:
+            assert torch.equal(s0[k], s1[k]), (penalty, k)  # replicas stay bit-identical either way
+        diffs[penalty] = max((s0[k] - ref[k]).abs().max().item() for k in ref)
+    assert diffs["global"] <= 1e-5, diffs
+    assert diffs["local"] > 10 * max(diffs["global"], 1e-7), diffs  # the per-rank norm is a different objective
+
+
+def test_step_state_survives_pickling_and_copy():
+    """Every module of a model carries the StepState: torch.save(model) / mp.spawn must not trip over it."""
+    import copy
+    import io
+    import pickle
+    from ac_tsr_amd.state import DEFAULT, StepState
+    st = StepState()
+    st.seed_salt, st.prune_dead_work = 12345, False
+    lin = torch.nn.Linear(3, 3)
+    st.attach(lin)
+    for clone in (pickle.loads(pickle.dumps(st)), copy.copy(st), copy.deepcopy(st)):
+        assert (clone.seed_salt, clone.prune_dead_work, clone.table_grad, clone.grad_home) == (12345, False, None, None)
+        clone.seed_salt = 1  # not frozen
+    buf = io.BytesIO()
+    torch.save(lin, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert back.__dict__["_step_state"].seed_salt == 12345
+    frozen = pickle.loads(pickle.dumps(DEFAULT))
+    with pytest.raises(AttributeError):
+        frozen.seed_salt = 3

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 pass() {
   local tag=$1; shift
   mkdir -p $R/gpurun_out/$name/$tag
-  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/$name/$tag -o $tag -- python3 $R/bench.py --kernel-only --kernel-iters 12 > $R/gpurun_out/$name/$tag/run.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/$name/$tag -o $tag -- python3 $R/bench.py --kernel-only --kernel-iters 12 --kernel-kinds ${KINDS:-ragged,spatial} > $R/gpurun_out/$name/$tag/run.log 2>&1
   echo "pass $tag rc=$?"
 }
 pass sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES || exit 1
