@@ -5,7 +5,8 @@ those of recbole/model/layers.py (AttackRMultiHeadAttention :614-742, FeedForwar
 AttackRTransformerLayer :859-951, AttackRTransformerEncoder :1070-1131), so a checkpoint of the
 reference loads with `load_state_dict` and the AC-SASRec trainer can drive these modules unchanged.
 The attention core itself is NOT a chain of torch ops: every layer makes one call into the HIP
-library (`ops.calibrated_attention`); the dense projections around it stay rocBLAS GEMMs.
+library (`ops.calibrated_attention`); the six projections in front of it are one launch (`linear.projections`: hidden 64, else
+hipBLASLt GEMMs in one autograd node), the position-wise tail behind it another (`tail.layer_tail`).
 
 Extra, optional keyword arguments (absent from the reference) are prefixed with an underscore:
 `_rnd` feeds explicit randomness for parity tests.
