@@ -256,4 +256,4 @@ def full_sort_cross_entropy_rows(output: torch.Tensor, table: torch.Tensor, targ
 
 
 def supported(hidden_size: int) -> bool:
-    return hidden_size in (64, 128)
+    return hidden_size in (64, 128, 256)

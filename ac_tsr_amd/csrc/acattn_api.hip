@@ -133,13 +133,13 @@ int acattn_rng_materialize(int32_t B, int32_t n_heads, int32_t L, uint64_t seed,
 static int check_ce(const acattn_ce_problem* p) {
   if (!p) return fail("ce problem is NULL");
   if (p->B < 1 || p->N < 1) return fail("B and N must be positive");
-  if (p->H != 64 && p->H != 128) return fail("unsupported hidden size for the fused cross-entropy: H must be 64 or 128");
+  if (p->H != 64 && p->H != 128 && p->H != 256) return fail("unsupported hidden size for the fused cross-entropy: H must be 64, 128 or 256");
   if (!p->out || !p->table || !p->target) return fail("out, table, target must be non-NULL");
   return 0;
 }
 
 int64_t acattn_full_sort_ce_workspace_bytes(const acattn_ce_problem* p) {
-  if (!p || (p->H != 64 && p->H != 128)) return -1;
+  if (!p || (p->H != 64 && p->H != 128 && p->H != 256)) return -1;
   return acattn_ce_ws_bytes(*p);
 }
 

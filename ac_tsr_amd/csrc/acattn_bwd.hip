@@ -14,7 +14,8 @@ int acattn_launch_bwd_stream(const acattn_problem& p, const acattn_bwd_io& io, h
 int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream);
 
 namespace {
-int g_bwd_kernel = ACATTN_BWD_AUTO;
+// per host thread: a measurement / test hook must not race with launches another thread issues
+thread_local int g_bwd_kernel = ACATTN_BWD_AUTO;
 }
 int acattn_bwd_kernel_choice(int which) {
   const int old = g_bwd_kernel;

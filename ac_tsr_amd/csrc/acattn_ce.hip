@@ -572,8 +572,10 @@ static int num_cus() {
   return n;
 }
 
+// (CH = 256: one tile per wave -- the wave's table rows, the batch rows and the d_table accumulators are 64 registers
+// each per tile, and the backward's LDS stage is 150 KB at one tile)
 template <int CH>
-constexpr int max_tiles() { return CH <= 64 ? 7 : 3; }
+constexpr int max_tiles() { return CH <= 64 ? 7 : (CH <= 128 ? 3 : 1); }
 
 // smallest tile count whose single round of (#CUs) workgroups covers N items
 template <int CH>
@@ -581,6 +583,7 @@ int pick_tiles(int N) {
   const int per_tile = num_cus() * CE_NW * 16;
   const int need = (N + per_tile - 1) / per_tile;
   if (CH <= 64) return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
+  if (CH > 128) return 1;
   return need <= 1 ? 1 : need <= 2 ? 2 : 3;
 }
 
@@ -653,6 +656,8 @@ int launch_fwd_dir_t(const acattn_ce_problem& p, void* ws, float* lse, float* ro
 
 template <int CH>
 int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, float* dir, hipStream_t stream) {
+  if constexpr (CH > 128) return launch_fwd_dir_t<CH, 1>(p, ws, lse, row_loss, dir, stream);
+  else
   switch (pick_tiles<CH>(p.N)) {
     case 1: return launch_fwd_dir_t<CH, 1>(p, ws, lse, row_loss, dir, stream);
     case 2: return launch_fwd_dir_t<CH, 2>(p, ws, lse, row_loss, dir, stream);
@@ -669,7 +674,7 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
   if (CH <= 64 && tiles == 3) tiles = 4;
   if (tiles > max_tiles<CH>()) tiles = max_tiles<CH>();
   const int64_t n_wg = (p.N + CE_NW * 16 * tiles - 1) / (CE_NW * 16 * tiles);
-  int ftiles = pick_tiles_fwd<CH>(p.N);
+  int ftiles = CH > 128 ? 1 : pick_tiles_fwd<CH>(p.N);
   if (CH <= 64 && ftiles == 3) ftiles = 4;
   if (ftiles > max_tiles<CH>()) ftiles = max_tiles<CH>();
   const int64_t n_wg_fwd = (p.N + CE_NW * 16 * ftiles - 1) / (CE_NW * 16 * ftiles);
@@ -683,6 +688,8 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
 
 template <int CH>
 int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
+  if constexpr (CH > 128) return launch_fwd_t<CH, 1>(p, ws, lse, row_loss, stream);
+  else
   switch (pick_tiles_fwd<CH>(p.N)) {
     case 1: return launch_fwd_t<CH, 1>(p, ws, lse, row_loss, stream);
     case 2: return launch_fwd_t<CH, 2>(p, ws, lse, row_loss, stream);
@@ -695,6 +702,8 @@ int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss
 template <int CH>
 int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out, float* d_table,
                hipStream_t stream) {
+  if constexpr (CH > 128) return launch_bwd_t<CH, 1>(p, lse, coef, ws, d_out, d_table, stream);
+  else
   switch (pick_tiles<CH>(p.N)) {
     case 1: return launch_bwd_t<CH, 1>(p, lse, coef, ws, d_out, d_table, stream);
     case 2: return launch_bwd_t<CH, 2>(p, lse, coef, ws, d_out, d_table, stream);
@@ -710,6 +719,7 @@ int64_t acattn_ce_ws_bytes(const acattn_ce_problem& p) {
   switch (p.H) {
     case 64: return ws_bytes<64>(p);
     case 128: return ws_bytes<128>(p);
+    case 256: return ws_bytes<256>(p);
   }
   return -1;
 }
@@ -718,6 +728,7 @@ int acattn_launch_ce_fwd(const acattn_ce_problem& p, void* ws, float* lse, float
   switch (p.H) {
     case 64: return launch_fwd<64>(p, ws, lse, row_loss, stream);
     case 128: return launch_fwd<128>(p, ws, lse, row_loss, stream);
+    case 256: return launch_fwd<256>(p, ws, lse, row_loss, stream);
   }
   return -1;
 }
@@ -727,6 +738,7 @@ int acattn_launch_ce_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, f
   switch (p.H) {
     case 64: return launch_fwd_dir<64>(p, ws, lse, row_loss, dir, stream);
     case 128: return launch_fwd_dir<128>(p, ws, lse, row_loss, dir, stream);
+    case 256: return launch_fwd_dir<256>(p, ws, lse, row_loss, dir, stream);
   }
   return -1;
 }
@@ -736,6 +748,7 @@ int acattn_launch_ce_bwd(const acattn_ce_problem& p, const float* lse, const flo
   switch (p.H) {
     case 64: return launch_bwd<64>(p, lse, coef, ws, d_out, d_table, stream);
     case 128: return launch_bwd<128>(p, lse, coef, ws, d_out, d_table, stream);
+    case 256: return launch_bwd<256>(p, lse, coef, ws, d_out, d_table, stream);
   }
   return -1;
 }

@@ -38,7 +38,8 @@ int acattn_launch_fwd_dma(const acattn_problem& p, const acattn_fwd_out& o, hipS
 int acattn_launch_fwd_stream(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream);
 
 namespace {
-int g_fwd_kernel = ACATTN_FWD_AUTO;
+// per host thread: a measurement / test hook must not race with launches another thread issues
+thread_local int g_fwd_kernel = ACATTN_FWD_AUTO;
 }
 int acattn_fwd_kernel_choice(int which) {
   const int old = g_fwd_kernel;

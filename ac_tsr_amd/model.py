@@ -403,19 +403,23 @@ class AcBERT4Rec(SequentialRecommender):
         (acbert4rec.py:201-209)."""
         table = self.item_embedding.weight[:self.n_items]
         rows = seq_output.reshape(-1, seq_output.size(-1))
-        if rows.is_cuda and ce.supported(self.hidden_size) and torch.is_grad_enabled():
+        # hidden 256: the fused kernels run one item tile per wave there (acattn_ce.hip) and are MEASURED slower than
+        # hipBLASLt + materialised logits for this model's ~20k masked slots (98.7 against 53.3 ms per step at 20k items,
+        # round 3) -- they are taken when the [rows, N] logits would not be reasonable to hold (`ce_materialise_limit`
+        # bytes per logits tensor, 16 GiB by default: 20k slots x 100k items is 8.2 GB and still materialises)
+        limit = getattr(self, "ce_materialise_limit", 16 << 30)
+        fused = rows.is_cuda and ce.supported(self.hidden_size) and torch.is_grad_enabled() and (
+            self.hidden_size <= 128 or rows.shape[0] * table.shape[0] * 4 > limit)
+        if fused:
             per_slot = ce.full_sort_cross_entropy_rows(rows, table, pos_items.reshape(-1), table_grad=not attack_loss,
                                                        state=self.step_state)
         else:
-            # hidden sizes the fused cross-entropy does not cover (256): materialised [rows, N] logits.  A deliberate
-            # choice for this model, not an omission: with ~20k masked slots per batch a recompute-based fused CE costs
-            # 5 catalogue products against 3, and the logits (1.6 GB at 20k x 20k) are < 1 % of the 288 GB of HBM
-            # (DESIGN.md section 8); said once per process so that nobody has to find it in a profile.
+            # said once per process so that nobody has to find it in a profile
             if rows.is_cuda and not getattr(AcBERT4Rec, "_noted_materialised_ce", False):
                 AcBERT4Rec._noted_materialised_ce = True
                 logging.getLogger("ac_tsr_amd").info(
-                    "AcBERT4Rec: hidden_size %d is outside the fused cross-entropy (64, 128); the masked-slot CE uses "
-                    "materialised [%d, %d] logits", self.hidden_size, rows.shape[0], table.shape[0])
+                    "AcBERT4Rec: hidden_size %d: the masked-slot CE uses materialised [%d, %d] logits (faster than the "
+                    "fused kernels at this width; ce_materialise_limit switches)", self.hidden_size, rows.shape[0], table.shape[0])
             per_slot = nn.functional.cross_entropy(full_sort_scores(rows, table, self.step_state), pos_items.reshape(-1),
                                                    reduction='none')
         return torch.sum(per_slot * targets) / torch.sum(targets)

@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--heads", type=int, default=2)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--inner", type=int, default=256)
-    ap.add_argument("--items", type=int, default=100000)
+    ap.add_argument("--items", type=int, default=None, help="catalogue size (default 100000; 20000 for --config cfg5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short measurements of the other named shapes (L=200 d=64, configs[3], configs[4])")
@@ -76,9 +76,12 @@ def parse():
         a.seq_len, a.hidden, a.heads, a.inner = 200, 128, 4, 512
     elif a.config == "cfg5":  # "AC-BERT4Rec variant (bidirectional mask) L=200 d=256"
         # heads: BASELINE leaves them open; 4 -> head size 64 (the reference default of 2 would need head size 128,
-        # which the kernels do not cover).  20,000 items: the masked-slot CE at d=256 goes through materialised
-        # [rows, N] logits (the fused CE covers d <= 128) and ~20 k rows x 100 k items would be 8 GB per tensor.
-        a.seq_len, a.hidden, a.heads, a.inner, a.items, a.model = 200, 256, 4, 1024, 20000, "AcBERT4Rec"
+        # which the tuned kernels do not cover).  20,000 items by default: the masked-slot CE at d=256 goes through
+        # materialised [rows, N] logits (measured faster than the fused kernels at this width, model.py) and ~20 k rows x
+        # 100 k items are 8 GB per logits tensor; `--items 100000` runs that too.
+        a.seq_len, a.hidden, a.heads, a.inner, a.model = 200, 256, 4, 1024, "AcBERT4Rec"
+        a.items = a.items or 20000
+    a.items = a.items or 100000
     return a
 
 

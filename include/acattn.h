@@ -160,7 +160,7 @@ typedef struct acattn_bwd_io {
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
  * recbole/model/sequential_recommender/acsasrec.py:117-120, without materialising the [B, N] logits. */
 typedef struct acattn_ce_problem {
-  int32_t B, N, H;       /* rows (sequences), catalogue size, hidden size (64 or 128) */
+  int32_t B, N, H;       /* rows (sequences), catalogue size, hidden size (64, 128 or 256) */
   const float* out;      /* [B,H] sequence representations (attacked_output / calibrated_output)  acsasrec.py:101-103 */
   const float* table;    /* [N,H] item_embedding.weight                                           acsasrec.py:117 */
   const int64_t* target; /* [B]   pos_items                                                      acsasrec.py:108 */
@@ -472,7 +472,8 @@ int acattn_rng_materialize(int32_t B, int32_t n_heads, int32_t L, uint64_t seed,
 
 /* Diagnostics / measurement: pin the forward kernel acattn_calibrated_attention_fwd dispatches to (process-wide).
  * Every kernel computes the same function; one that does not cover the problem (options, L, rng mode) is skipped
- * and the automatic choice applies.  Returns the previous setting. */
+ * and the automatic choice applies.  Returns the previous setting.  The setting is PER HOST THREAD (thread_local): it
+ * affects the launches the calling thread issues afterwards and nobody else's. */
 enum {
   ACATTN_FWD_AUTO = 0,    /* streaming kernel where it applies (training configuration, L <= 208), else general */
   ACATTN_FWD_STREAM = 1,  /* acattn_fwd_stream.hip: one wave per 16-row query block, no LDS staging (L <= 208) */

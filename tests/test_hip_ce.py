@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("B,N,H", [(512, 100000, 64), (37, 1000, 64), (16, 257, 64), (130, 5003, 128), (1, 64, 64)])
+@pytest.mark.parametrize("B,N,H", [(512, 100000, 64), (37, 1000, 64), (16, 257, 64), (130, 5003, 128), (1, 64, 64),
+                                   (130, 5003, 256), (2100, 20011, 256)])
 @pytest.mark.parametrize("scale", [0.02, 1.0])
 def test_fused_ce_matches_materialised_logits(B, N, H, scale):
     g = torch.Generator().manual_seed(B + N)
@@ -42,7 +43,8 @@ def test_fused_ce_without_table_gradient():
     assert (d_o - g_o).abs().max() <= 1e-5
 
 
-@pytest.mark.parametrize("B,N,H", [(512, 100000, 64), (37, 1000, 64), (16, 257, 64), (130, 5003, 128), (1, 64, 64), (5, 449, 64)])
+@pytest.mark.parametrize("B,N,H", [(512, 100000, 64), (37, 1000, 64), (16, 257, 64), (130, 5003, 128), (1, 64, 64), (5, 449, 64),
+                                   (70, 3001, 256)])
 @pytest.mark.parametrize("scale", [0.02, 1.0, 4.0])
 def test_forward_with_direction_matches_materialised_logits(B, N, H, scale):
     """table_grad=False (acattn_full_sort_ce_fwd_dir): loss and d_out from ONE sweep, for row weights of both signs;
