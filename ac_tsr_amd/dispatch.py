@@ -1,0 +1,189 @@
+"""The fused core as torch dispatcher operators: `torch.ops.acattn.calibrated_attention_fwd / _bwd`.
+
+SURVEY.md section 8(b) asks for the native side to sit behind a torch custom op.  The library itself stays a plain C ABI
+(include/acattn.h: no torch types in it, any host can bind it); this module registers that ABI's two attention entry
+points with the dispatcher (`torch.library`), in the form the training step uses -- structured mask, counter RNG, `gate`
+combine, two_level -- so that
+
+  * the launches are visible to the dispatcher (profiler op names, `torch.library.opcheck`, FakeTensor / meta tracing: each
+    op has a Meta implementation that only computes shapes),
+  * `calibrated_attention_fwd` carries an autograd formula of its own (`register_autograd`: a caller of the raw op gets
+    gradients without ops._CalibratedAttention), and
+  * ops._CalibratedAttention routes its launches through them when the call has that form (`ops.USE_DISPATCHER`), so the
+    operators tested here are the operators that train.
+
+The options outside that form (dense masks, explicit randomness for parity tests, 'fixed' / 'annealing', one-level,
+probability dumps) keep the direct C-ABI call in ops.py.  Reference semantics: recbole/model/layers.py:657-742, 883-936,
+677-680 (see ops.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_LIB = torch.library.Library("acattn", "DEF")
+_LIB.define(
+    "calibrated_attention_fwd(Tensor q, Tensor k, Tensor v, Tensor? qa, Tensor? ka, Tensor? gate, Tensor key_valid, "
+    "bool causal, Tensor w_order, Tensor b_order, Tensor w_dist, Tensor b_dist, Tensor scalar, int n_heads, "
+    "float p_drop, int seed, Tensor? seed_tensor, bool gate_is_prob, Tensor? affine, bool adversarial) "
+    "-> (Tensor, Tensor, Tensor, Tensor)")
+_LIB.define(
+    "calibrated_attention_bwd(Tensor q, Tensor k, Tensor v, Tensor qa, Tensor ka, Tensor gate, Tensor key_valid, "
+    "bool causal, Tensor w_order, Tensor b_order, Tensor w_dist, Tensor b_dist, Tensor scalar, int n_heads, "
+    "float p_drop, int seed, Tensor? seed_tensor, bool gate_is_prob, Tensor attack_mask, Tensor row_stats, "
+    "Tensor? d_ctx_attacked, Tensor? d_ctx_calibrated, Tensor? d_attack_mask, Tensor? read_rows, Tensor? active_qblocks, "
+    "bool attack_only) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _problem(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
+             seed_tensor, gate_is_prob, affine, adversarial) -> _lib.Problem:
+    B, L, H = q.shape
+    p = _lib.Problem()
+    p.B, p.L, p.H, p.n_heads = B, L, H, n_heads
+    p.q, p.k, p.v = _ptr(q), _ptr(k), _ptr(v)
+    p.adversarial = int(adversarial)
+    if adversarial:
+        p.qa, p.ka, p.gate_logits = _ptr(qa), _ptr(ka), _ptr(gate)
+        p.gate_is_prob = int(gate_is_prob)
+    p.combine_option, p.two_level = _lib.COMBINE["gate"], 1
+    p.mask_mode, p.causal, p.key_valid = _lib.MASK_STRUCTURED, int(causal), _ptr(key_valid)
+    p.w_order, p.b_order, p.w_dist, p.b_dist, p.scalar = (_ptr(t) for t in (w_order, b_order, w_dist, b_dist, scalar))
+    p.affine = _ptr(affine)
+    p.rng_mode, p.p_drop, p.seed = _lib.RNG_COUNTER, float(p_drop), seed & 0xFFFFFFFFFFFFFFFF
+    p.seed_device = _ptr(seed_tensor)
+    return p
+
+
+def _check_inputs(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.AcattnError(f"acattn operators run only as HIP kernels on an MI355X (got a tensor on {t.device}): "
+                                   "no CPU fallback")
+        if not t.is_contiguous():
+            raise ValueError("acattn operators take contiguous tensors")
+
+
+def _fwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
+              seed_tensor, gate_is_prob, affine, adversarial):
+    _check_inputs(q, k, v, qa, ka, gate, key_valid, w_order, b_order, w_dist, b_dist, scalar, seed_tensor, affine)
+    B, L, H = q.shape
+    prob = _problem(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop,
+                    seed, seed_tensor, gate_is_prob, affine, adversarial)
+    out = _lib.FwdOut()
+    ctx_cal = torch.empty_like(q)
+    out.ctx_calibrated = _ptr(ctx_cal)
+    if adversarial:
+        ctx_att = torch.empty_like(q)
+        M = torch.empty(B, n_heads, L, L, device=q.device, dtype=torch.float32)
+        stats = torch.empty(B, n_heads, L, _lib.NSTAT, device=q.device, dtype=torch.float32)
+        out.ctx_attacked, out.attack_mask, out.row_stats = _ptr(ctx_att), _ptr(M), _ptr(stats)
+    else:  # the spatial-only operator writes one context; the other outputs are empty
+        ctx_att, M, stats = (q.new_empty(0) for _ in range(3))
+    _lib.check(_lib.load().acattn_calibrated_attention_fwd(C.byref(prob), C.byref(out), _stream()), "calibrated_attention_fwd")
+    return ctx_att, ctx_cal, M, stats
+
+
+def _fwd_meta(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
+              seed_tensor, gate_is_prob, affine, adversarial):
+    B, L, H = q.shape
+    if adversarial:
+        return (torch.empty_like(q), torch.empty_like(q), q.new_empty(B, n_heads, L, L), q.new_empty(B, n_heads, L, _lib.NSTAT))
+    return q.new_empty(0), torch.empty_like(q), q.new_empty(0), q.new_empty(0)
+
+
+def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
+              seed_tensor, gate_is_prob, attack_mask, row_stats, d_ctx_attacked, d_ctx_calibrated, d_attack_mask, read_rows,
+              active_qblocks, attack_only):
+    _check_inputs(q, k, v, qa, ka, gate, key_valid, attack_mask, row_stats, d_ctx_attacked, d_ctx_calibrated, d_attack_mask,
+                  read_rows, active_qblocks)
+    lib = _lib.load()
+    B, L, H = q.shape
+    dh = H // n_heads
+    prob = _problem(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop,
+                    seed, seed_tensor, gate_is_prob, None, True)
+    io = _lib.BwdIO()
+    io.attack_mask, io.row_stats = _ptr(attack_mask), _ptr(row_stats)
+    io.d_ctx_attacked, io.d_ctx_calibrated, io.d_attack_mask = _ptr(d_ctx_attacked), _ptr(d_ctx_calibrated), _ptr(d_attack_mask)
+    dq, dk, dv, dqa, dka = (torch.empty_like(q) for _ in range(5))
+    io.dq, io.dk, io.dv, io.dqa, io.dka = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqa), _ptr(dka)
+    dgate_part = torch.empty(B, n_heads, L, L, device=q.device, dtype=torch.float32)
+    io.dgate_logits = _ptr(dgate_part)
+    # the three per-(b, head) partial sums share ONE [B*nh, 4*dh + 4] buffer, reduced in a single pass by the caller
+    width = 4 * dh + 4
+    part = torch.empty(B * n_heads, width, device=q.device, dtype=torch.float32)
+    ws_bytes = int(lib.acattn_calibrated_attention_bwd_workspace_bytes(C.byref(prob)))
+    ws = torch.empty(max(ws_bytes, 4) // 4, device=q.device, dtype=torch.float32)
+    io.workspace = _ptr(ws)
+    base = part.data_ptr()
+    io.dw_order_part, io.dw_dist_part, io.dsmall_part = base, base + 4 * 2 * dh, base + 4 * 4 * dh
+    io.part_stride = width
+    io.active_qblocks = _ptr(active_qblocks)
+    if read_rows is not None:
+        io.read_rows, io.n_read_rows = _ptr(read_rows), read_rows.shape[1]
+    io.attack_only = int(attack_only)
+    _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
+    return dq, dk, dv, dqa, dka, dgate_part, part
+
+
+def _bwd_meta(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
+              seed_tensor, gate_is_prob, attack_mask, row_stats, d_ctx_attacked, d_ctx_calibrated, d_attack_mask, read_rows,
+              active_qblocks, attack_only):
+    B, L, H = q.shape
+    dh = H // n_heads
+    e = lambda: torch.empty_like(q)
+    return e(), e(), e(), e(), e(), q.new_empty(B, n_heads, L, L), q.new_empty(B * n_heads, 4 * dh + 4)
+
+
+_LIB.impl("calibrated_attention_fwd", _fwd_cuda, "CUDA")
+_LIB.impl("calibrated_attention_fwd", _fwd_meta, "Meta")
+_LIB.impl("calibrated_attention_bwd", _bwd_cuda, "CUDA")
+_LIB.impl("calibrated_attention_bwd", _bwd_meta, "Meta")
+
+
+# ---- autograd formula of the raw forward op (a caller that bypasses ops._CalibratedAttention) ---------------------------------
+def _setup_context(ctx, inputs, output):
+    (q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed, seed_tensor,
+     gate_is_prob, affine, adversarial) = inputs
+    if not adversarial:
+        ctx.adversarial = False
+        return
+    ctx.adversarial = True
+    ctx.args = (causal, n_heads, p_drop, seed, gate_is_prob)
+    ctx.save_for_backward(q, k, v, qa, ka, gate, key_valid, w_order, b_order, w_dist, b_dist, scalar,
+                          seed_tensor if seed_tensor is not None else q.new_empty(0), output[2], output[3])
+    ctx.has_seed_tensor = seed_tensor is not None
+    ctx.set_materialize_grads(False)
+
+
+def _backward(ctx, d_att, d_cal, d_M, _d_stats):
+    if not ctx.adversarial:
+        raise _lib.AcattnError("backward of the spatial-only operator is not provided")
+    q, k, v, qa, ka, gate, key_valid, w_order, b_order, w_dist, b_dist, scalar, seed_t, M, stats = ctx.saved_tensors
+    causal, n_heads, p_drop, seed, gate_is_prob = ctx.args
+    con = lambda t: None if t is None else t.contiguous()
+    dq, dk, dv, dqa, dka, dgate_part, part = torch.ops.acattn.calibrated_attention_bwd(
+        q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
+        seed_t if ctx.has_seed_tensor else None, gate_is_prob, M, stats, con(d_att), con(d_cal), con(d_M), None, None, False)
+    dh = q.shape[-1] // n_heads
+    tot = part.sum(0)
+    small = tot[4 * dh:]
+    return (dq, dk, dv, dqa, dka, dgate_part.sum(1), None, None, tot[:2 * dh].view_as(w_order), small[0:1].view_as(b_order),
+            tot[2 * dh:4 * dh].view_as(w_dist), small[1:2].view_as(b_dist), small[2:3].view_as(scalar), None, None, None, None,
+            None, None, None)
+
+
+torch.library.register_autograd("acattn::calibrated_attention_fwd", _backward, setup_context=_setup_context, lib=_LIB)

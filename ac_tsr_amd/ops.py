@@ -170,6 +170,17 @@ def _fill_problem(q, k, v, qa, ka, gate_logits, mask, w_order, b_order, w_dist, 
     return prob
 
 
+# Route the launches of the training form (structured mask, counter RNG, `gate`, two_level, both spatial terms, no
+# probability dumps) through the dispatcher operators of dispatch.py (torch.ops.acattn.*); everything else, and every call
+# when this is False, goes to the C ABI directly.  Same kernels either way.
+USE_DISPATCHER = True
+
+
+def _dispatcher_form(cfg, mask, rnd, want_probs, w_order, w_dist) -> bool:
+    return (USE_DISPATCHER and isinstance(mask, StructuredMask) and rnd is None and not want_probs and cfg.two_level
+            and w_order is not None and w_dist is not None and (not cfg.adversarial or cfg.combine_option == "gate"))
+
+
 class _CalibratedAttention(torch.autograd.Function):
     """Inputs that can carry gradients are the first 12 positional tensors; the rest is configuration."""
 
@@ -197,9 +208,27 @@ class _CalibratedAttention(torch.autograd.Function):
         keep = []
         wo = w_order.reshape(-1) if w_order is not None else None
         wd = w_dist.reshape(-1) if w_dist is not None else None
+        ctx.gate_is_prob = gate_is_prob  # the backward reads the same tensor the same way; the planes are forward-only
+        ctx.via_dispatcher = _dispatcher_form(cfg, mask, rnd, want_probs, w_order, w_dist)
+        if ctx.via_dispatcher:
+            from . import dispatch  # noqa: F401  (registers torch.ops.acattn.*)
+            for name, t in (("q", q), ("k", k), ("v", v)):
+                _need_cuda(name, t)
+            if cfg.adversarial and gate_logits.shape != (B, L, L):
+                # same failure as the reference's broadcast at layers.py:888 when seq_length != L
+                raise RuntimeError(f"The size of tensor a ({gate_logits.shape[-1]}) must match the size of tensor b ({L})")
+            ctx_att, ctx_cal, M, stats = torch.ops.acattn.calibrated_attention_fwd(
+                q, k, v, qa if cfg.adversarial else None, ka if cfg.adversarial else None,
+                gate_logits if cfg.adversarial else None, mask.key_valid, bool(mask.causal), wo.contiguous(), b_order,
+                wd.contiguous(), b_dist, scalar, nh, float(p_drop), int(seed) & 0x7FFFFFFFFFFFFFFF, seed_tensor,
+                bool(gate_is_prob), affine, bool(cfg.adversarial))
+            if not cfg.adversarial:
+                ctx_att = M = stats = None
+            ctx.cfg, ctx.p_drop, ctx.rnd, ctx.seed, ctx.mask, ctx.seed_tensor = cfg, p_drop, rnd, seed, mask, seed_tensor
+            ctx.save_for_backward(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats)
+            return (ctx_att, ctx_cal, M, None, None, None, None)
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
                              p_drop, rnd, seed, keep, seed_tensor, gate_is_prob, affine)
-        ctx.gate_is_prob = gate_is_prob  # the backward reads the same tensor the same way; the planes are forward-only
         out = FwdOut()
         ctx_cal = torch.empty_like(q)
         out.ctx_calibrated = _ptr(ctx_cal)
@@ -236,13 +265,21 @@ class _CalibratedAttention(torch.autograd.Function):
         keep = []
         wo = w_order.reshape(-1) if w_order is not None else None
         wd = w_dist.reshape(-1) if w_dist is not None else None
+        d_att = None if d_att is None else d_att.contiguous()
+        d_cal = None if d_cal is None else d_cal.contiguous()
+        d_M = None if d_M is None else d_M.contiguous()
+        if ctx.via_dispatcher:
+            attack_only = ctx.state.attack_pass_only and not ctx.attack_upstream
+            dq, dk, dv, dqa, dka, dgate_part, part = torch.ops.acattn.calibrated_attention_bwd(
+                q, k, v, qa, ka, gate_logits, ctx.mask.key_valid, bool(ctx.mask.causal), wo.contiguous(), b_order,
+                wd.contiguous(), b_dist, scalar, nh, float(ctx.p_drop), int(ctx.seed) & 0x7FFFFFFFFFFFFFFF, ctx.seed_tensor,
+                bool(ctx.gate_is_prob), M, stats, d_att, d_cal, d_M, ctx.read_rows, ctx.active_qblocks, bool(attack_only))
+            return _CalibratedAttention._finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh,
+                                                         w_order, b_order, w_dist, b_dist, scalar, rich_ratio)
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, ctx.mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
                              ctx.p_drop, ctx.rnd, ctx.seed, keep, ctx.seed_tensor, ctx.gate_is_prob)
         io = BwdIO()
         io.attack_mask, io.row_stats = _ptr(M), _ptr(stats)
-        d_att = None if d_att is None else d_att.contiguous()
-        d_cal = None if d_cal is None else d_cal.contiguous()
-        d_M = None if d_M is None else d_M.contiguous()
         io.d_ctx_attacked, io.d_ctx_calibrated, io.d_attack_mask = _ptr(d_att), _ptr(d_cal), _ptr(d_M)
         dq, dk, dv, dqa, dka = (torch.empty_like(q) for _ in range(5))
         io.dq, io.dk, io.dv, io.dqa, io.dka = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqa), _ptr(dka)
@@ -268,6 +305,14 @@ class _CalibratedAttention(torch.autograd.Function):
         attack_only = ctx.state.attack_pass_only and not ctx.attack_upstream
         io.attack_only = int(attack_only)
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
+        return _CalibratedAttention._finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh, w_order,
+                                                     b_order, w_dist, b_dist, scalar, rich_ratio)
+
+    @staticmethod
+    def _finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh, w_order, b_order, w_dist, b_dist,
+                         scalar, rich_ratio):
+        """The reductions behind the backward launch: per-head gate partials and per-(b, head) parameter partials."""
+        dgate = None
         if attack_only:
             return (None, None, None, dqa, dka) + (None,) * 19
         if dgate_part is not None and dgate_part.shape[1] > 1 and part.shape[0] < 4096:

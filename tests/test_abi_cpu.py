@@ -128,3 +128,30 @@ def test_module_surface_matches_reference_state_dict_keys():
     m.load_state_dict(ref)  # a reference checkpoint loads as is
     attack = [n for n, _ in m.named_parameters() if A.is_attack_param(n)]
     assert len(attack) == 4 * cfg.enc.n_layers
+
+
+def test_dispatcher_operators_are_registered_with_shape_functions():
+    """ac_tsr_amd/dispatch.py registers the two attention entry points with torch's dispatcher; without a GPU the Meta
+    implementations (shapes only) are what can run, and a CPU tensor must be refused, not computed."""
+    import torch
+    from ac_tsr_amd import dispatch  # noqa: F401
+    B, L, H, nh = 3, 50, 64, 2
+    q = torch.empty(B, L, H, device="meta")
+    kv = torch.empty(B, L, dtype=torch.uint8, device="meta")
+    w, b1 = torch.empty(2 * H // nh, device="meta"), torch.empty(1, device="meta")
+    gate = torch.empty(B, L, L, device="meta")
+    ctx_a, ctx_c, M, stats = torch.ops.acattn.calibrated_attention_fwd(q, q, q, q, q, gate, kv, True, w, b1, w, b1, b1, nh, 0.5, 1,
+                                                                        None, False, None, True)
+    assert ctx_a.shape == ctx_c.shape == (B, L, H) and M.shape == (B, nh, L, L) and stats.shape == (B, nh, L, _lib.NSTAT)
+    outs = torch.ops.acattn.calibrated_attention_bwd(q, q, q, q, q, gate, kv, True, w, b1, w, b1, b1, nh, 0.5, 1, None, False, M,
+                                                     stats, q, q, M, None, None, False)
+    assert [tuple(t.shape) for t in outs] == [(B, L, H)] * 5 + [(B, nh, L, L), (B * nh, 4 * (H // nh) + 4)]
+    spatial = torch.ops.acattn.calibrated_attention_fwd(q, q, q, None, None, None, kv, True, w, b1, w, b1, b1, nh, 0.0, 1, None,
+                                                        False, None, False)
+    assert spatial[1].shape == (B, L, H) and spatial[0].numel() == 0
+    cpu = torch.zeros(B, L, H)
+    with pytest.raises(Exception):  # no CPU kernel is registered: the dispatcher refuses
+        torch.ops.acattn.calibrated_attention_fwd(cpu, cpu, cpu, cpu, cpu, torch.zeros(B, L, L), torch.ones(B, L, dtype=torch.uint8),
+                                                  True, torch.zeros(64), torch.zeros(1), torch.zeros(64), torch.zeros(1),
+                                                  torch.zeros(1), nh, 0.5, 1, None, False, None, True)
+

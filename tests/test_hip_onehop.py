@@ -231,3 +231,50 @@ def test_encoder_layer_equals_itself_without_producer_extras():
         assert (a - b).abs().max().item() <= 2e-5
     for (n, _), a, b in zip([("x", None)] + list(layer.named_parameters()), res[0][3], res[1][3]):
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-5, n
+
+
+def test_dispatcher_operators_equal_the_direct_c_abi_path():
+    """torch.ops.acattn.calibrated_attention_fwd / _bwd (ac_tsr_amd/dispatch.py): the raw operator with its own autograd
+    formula, the autograd node routed through it (the default) and the node on the direct C-ABI path give the same
+    outputs and gradients; the operator passes torch.library.opcheck's schema / fake-tensor checks."""
+    from ac_tsr_amd import dispatch  # noqa: F401
+    B, L, H, nh = 24, 50, 64, 2
+    t, kv, lens, g = _problem(B, L, H, nh, seed=31)
+    names = ["q", "k", "v", "qa", "ka", "gl", "w_order", "b_order", "w_dist", "b_dist", "scalar"]
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
+    mask = A.StructuredMask(kv.to(DEV), causal=True)
+    cot = [torch.randn(B, L, H, generator=g).to(DEV), torch.randn(B, L, H, generator=g).to(DEV),
+           torch.randn(B, nh, L, L, generator=g).to(DEV)]
+    seed, p_drop = 4711, 0.5
+
+    def via_node(use_dispatcher):
+        ops.USE_DISPATCHER = use_dispatcher
+        try:
+            dev = {k: t[k].to(DEV).requires_grad_(True) for k in names}
+            out = A.calibrated_attention(dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev["gl"], mask, cfg, p_drop=p_drop,
+                                         seed=seed, **{k: dev[k] for k in names[6:]})
+            loss = sum((o * c).sum() for o, c in zip(out[:3], cot))
+            return out[:3], torch.autograd.grad(loss, [dev[k] for k in names])
+        finally:
+            ops.USE_DISPATCHER = True
+
+    def via_raw_op():
+        dev = {k: t[k].to(DEV).requires_grad_(True) for k in names}
+        out = torch.ops.acattn.calibrated_attention_fwd(
+            dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev["gl"], mask.key_valid, True, dev["w_order"].reshape(-1),
+            dev["b_order"], dev["w_dist"].reshape(-1), dev["b_dist"], dev["scalar"], nh, p_drop, seed, None, False, None, True)
+        loss = sum((o * c).sum() for o, c in zip(out[:3], cot))
+        return out[:3], torch.autograd.grad(loss, [dev[k] for k in names])
+
+    ref_out, ref_g = via_node(False)
+    for got_out, got_g in (via_node(True), via_raw_op()):
+        for a, b in zip(got_out, ref_out):
+            assert torch.equal(a, b)
+        for n, a, b in zip(names, got_g, ref_g):
+            assert (a.reshape(b.shape) - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-9, n
+    dev = {k: t[k].to(DEV) for k in names}
+    torch.library.opcheck(torch.ops.acattn.calibrated_attention_fwd.default,
+                          (dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev["gl"], mask.key_valid, True,
+                           dev["w_order"].reshape(-1), dev["b_order"], dev["w_dist"].reshape(-1), dev["b_dist"], dev["scalar"],
+                           nh, p_drop, seed, None, False, None, True),
+                          test_utils=("test_schema", "test_faketensor"))
