@@ -87,7 +87,7 @@ class ProjOut(C.Structure):
 
 class ProjBwdIO(C.Structure):
     _fields_ = [("dmq", _f), ("dmk", _f), ("dmv", _f), ("dqa", _f), ("dka", _f), ("dgate", _f), ("dmq_total", _f),
-                ("dmk_total", _f), ("dx", _f), ("dx_init", _f)]
+                ("dmk_total", _f), ("dx", _f), ("dx_init", _f), ("workspace", _f)]
 
 
 ADAM_MAX_TENSORS = 64
@@ -142,6 +142,7 @@ SYMBOLS = {
     "acattn_embed_layernorm_fwd": (C.c_int, [C.POINTER(EmbedProblem), _f, _f, C.c_void_p]),
     "acattn_embed_layernorm_bwd": (C.c_int, [C.POINTER(EmbedProblem), _f, _f, C.c_int64, _f, _f, _f, C.c_void_p]),
     "acattn_projections_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "acattn_projections_bwd_workspace_bytes": (C.c_int64, [C.POINTER(ProjProblem)]),
     "acattn_projections_fwd": (C.c_int, [C.POINTER(ProjProblem), C.POINTER(ProjOut), C.c_void_p]),
     "acattn_projections_bwd": (C.c_int, [C.POINTER(ProjProblem), C.POINTER(ProjBwdIO), C.c_void_p]),
     "acattn_layer_tail_supported": (C.c_int, [C.c_int32, C.c_int32]),

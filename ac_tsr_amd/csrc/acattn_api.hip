@@ -199,7 +199,7 @@ int acattn_dropout_add_layernorm_bwd(const acattn_ln_problem* p, const float* dy
 static int check_proj(const acattn_proj_problem* p) {
   if (!p) return fail("problem must be non-NULL");
   if (p->rows < 1) return fail("rows must be positive");
-  if (!acattn_proj_supported(p->H, p->G)) return fail("projections: hidden_size must be 64 and the gate at most 256 wide");
+  if (!acattn_proj_supported(p->H, p->G)) return fail("projections: hidden_size must be 64, 128 or 256 and the gate at most 256 wide");
   if (!p->x || !p->wq || !p->bq || !p->wk || !p->bk || !p->wv || !p->bv || !p->waq || !p->baq || !p->wak || !p->bak)
     return fail("projections: input and parameters must be non-NULL");
   if ((p->wg != nullptr) != (p->bg != nullptr) || (p->wg != nullptr) != (p->G > 0))
@@ -208,6 +208,11 @@ static int check_proj(const acattn_proj_problem* p) {
 }
 
 int acattn_projections_supported(int32_t H, int32_t G) { return acattn_proj_supported(H, G) ? 1 : 0; }
+
+int64_t acattn_projections_bwd_workspace_bytes(const acattn_proj_problem* p) {
+  if (!p || !acattn_proj_supported(p->H, p->G)) return -1;
+  return acattn_proj_bwd_ws_bytes(*p);
+}
 
 int acattn_projections_fwd(const acattn_proj_problem* p, const acattn_proj_out* out, void* stream) {
   if (int rc = check_proj(p)) return rc;

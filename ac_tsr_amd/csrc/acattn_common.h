@@ -327,6 +327,7 @@ int acattn_launch_sum_rows_pair(const float* x1, float* out1, int batch1, int R1
                                 int batch2, int R2, int C2, hipStream_t stream);
 void acattn_set_error(const char* msg);
 bool acattn_proj_supported(int H, int G);
+int64_t acattn_proj_bwd_ws_bytes(const acattn_proj_problem& p);
 int acattn_launch_proj_fwd(const acattn_proj_problem& p, const acattn_proj_out& o, hipStream_t stream);
 int acattn_launch_proj_bwd(const acattn_proj_problem& p, const acattn_proj_bwd_io& io, hipStream_t stream);
 bool acattn_tail_supported(int H, int I);

@@ -139,12 +139,16 @@ __device__ __forceinline__ void write_affine(const f4 (&v)[NB][DT], const Rows<N
   constexpr float kL2e = 1.44269504088896340736f;
   const int nh = P.n_heads, dh = (16 * DT) / nh, tph = dh >> 4;  // 16-feature tiles per head
   const int LP = ((P.L + 15) >> 4) << 4;
-  f4 wo[DT], wd[DT];
+  // the two vectors' tiles: all requested up front where the registers allow it (hidden <= 128), else tile by tile
+  constexpr int PRE = DT <= 8 ? DT : 1;
+  f4 wo_[PRE], wd_[PRE];
+  if constexpr (DT <= 8) {
 #pragma unroll
-  for (int nt = 0; nt < DT; ++nt) {
-    const int f0 = woff + (16 * nt) % dh + 4 * g;
-    wo[nt] = *(const f4*)(P.w_order + f0);
-    wd[nt] = *(const f4*)(P.w_dist + f0);
+    for (int nt = 0; nt < DT; ++nt) {
+      const int f0 = woff + (16 * nt) % dh + 4 * g;
+      wo_[nt] = *(const f4*)(P.w_order + f0);
+      wd_[nt] = *(const f4*)(P.w_dist + f0);
+    }
   }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -152,10 +156,19 @@ __device__ __forceinline__ void write_affine(const f4 (&v)[NB][DT], const Rows<N
     float so = 0.f, sd = 0.f;
 #pragma unroll
     for (int nt = 0; nt < DT; ++nt) {
+      f4 wo, wd;
+      if constexpr (DT <= 8) {
+        wo = wo_[nt];
+        wd = wd_[nt];
+      } else {
+        const int f0 = woff + (16 * nt) % dh + 4 * g;
+        wo = *(const f4*)(P.w_order + f0);
+        wd = *(const f4*)(P.w_dist + f0);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        so = fmaf(v[nb][nt][r], wo[nt][r], so);
-        sd = fmaf(v[nb][nt][r], wd[nt][r], sd);
+        so = fmaf(v[nb][nt][r], wo[r], so);
+        sd = fmaf(v[nb][nt][r], wd[r], sd);
       }
       if ((nt + 1) % tph == 0) {  // head complete (wave-uniform)
         const float o = quad_sum(so), d = quad_sum(sd);
@@ -381,6 +394,304 @@ __global__ void __launch_bounds__(64) proj_bwd_kernel(const acattn_proj_problem 
   }
 }
 
+// =====================================================================================================================
+// Hidden sizes 128 and 256 (BASELINE configs[3], [4]) [round 3].  The H = 64 kernels above hold a product's whole weight
+// matrix as MFMA fragments (two sets of H^2 / 64 registers); at H = 128 that is 512 registers.  Here the weights STREAM:
+// one 16-row output tile of W at a time (H / 16 float4 per lane), the next tile requested while the current one is on
+// the matrix cores, two waves per SIMD covering what is left of the latency.  What stays in registers is what the chain
+// needs: the input rows x, and mq / mk between the product that makes them and the products that consume them.  The
+// backward uses the same streamed product on TRANSPOSED copies of the weights (a 0.5 MB workspace filled by
+// transpose_weights_kernel in front of it: the dword gathers of the H = 64 backward would be 256 per product here).
+// ---------------------------------------------------------------------------------------------------------------------
+// weights travel in chunks of KT = 8 contraction tiles (128 input features: 8 float4 per lane); H = 256 has two per tile
+constexpr int KT = 8;
+// timing-only probe builds (tools/probe/build_proj_variant.sh; results are WRONG with any of them):
+//   ACATTN_PROJ_W0       every tile reads weight tile 0 (what the weight stream itself costs)
+//   ACATTN_PROJ_NOSTORE  no output stores                (what the output traffic costs)
+//   ACATTN_PROJ_NB1      one row block per wave at hidden 128
+__device__ __forceinline__ void load_wchunk(const float* w, int ld, int n_out, int nt, int kc, int c, int g, f4 (&frag)[KT]) {
+#ifdef ACATTN_PROJ_W0
+  nt = 0;
+#endif
+  const int o = min(16 * nt + c, n_out - 1);
+#pragma unroll
+  for (int t = 0; t < KT; ++t) frag[t] = *(const f4*)(w + (size_t)o * ld + 16 * (KT * kc + t) + 4 * g);
+}
+
+template <int DT, int NB>
+__device__ __forceinline__ void chunk_product(const f4 (&w)[KT], int kc, const f4 (&in)[NB][DT], f4 (&acc)[NB]) {
+  static_for<DT / KT>([&](auto q) {  // kc is a run-time value in product_emit; the register index must not be
+    constexpr int KC = decltype(q)::value;
+    if (kc != KC) return;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(w[t][r], in[nb][KT * KC + t][r], acc[nb]);
+  });
+}
+
+// a tile's four bias values per lane, requested BEFORE the tile's weights: the memory counter retires in order, so a
+// bias asked for after the next tile's weights would make the wait for it a wait for those weights too
+__device__ __forceinline__ f4 bias_tile(const float* bias, int n_out, int nt, int g) {
+  f4 b = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+    const int j0 = 16 * nt + 4 * g;
+    if (j0 + 3 < n_out) {
+      b = *(const f4u*)(bias + j0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[r] = bias[min(j0 + r, n_out - 1)];
+    }
+  }
+  return b;
+}
+
+// acc[nb][nt] (+)= W[16 nt ..][:] . in^T for nt = 0 .. DT - 1, kept in registers; the steps (tile, chunk) are unrolled
+// (register arrays want compile-time indices), the weights one step ahead in two rotating buffers.  INIT: start from
+// the bias instead of from what acc holds.
+template <int DT, int NB, bool INIT>
+__device__ __forceinline__ void product_keep(const float* w, const float* bias, int c, int g, const f4 (&in)[NB][DT],
+                                             f4 (&acc)[NB][DT]) {
+  constexpr int H = 16 * DT, KC = DT / KT;
+  f4 wbuf[2][KT], bb[2];
+  if constexpr (INIT) bb[0] = bias_tile(bias, H, 0, g);
+  load_wchunk(w, H, H, 0, 0, c, g, wbuf[0]);
+  static_for<DT * KC>([&](auto k) {
+    constexpr int S = decltype(k)::value, NT = S / KC, C0 = S % KC;
+    if constexpr (S + 1 < DT * KC) {
+      if constexpr (INIT && (S + 1) % KC == 0) bb[((S + 1) / KC) & 1] = bias_tile(bias, H, (S + 1) / KC, g);
+      load_wchunk(w, H, H, (S + 1) / KC, (S + 1) % KC, c, g, wbuf[(S + 1) & 1]);
+    }
+    PIN_ORDER();
+    f4 a[NB];
+    if constexpr (INIT && C0 == 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) a[nb] = bb[NT & 1];
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) a[nb] = acc[nb][NT];
+    }
+    chunk_product<DT, NB>(wbuf[S & 1], C0, in, a);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb][NT] = a[nb];
+  });
+}
+
+// the same for ceil(n_out / 16) output tiles that are only EMITTED (stored), tile index at run time; two steps per trip
+// (two tiles at H = 128, the two chunks of one tile at H = 256)
+template <int DT, int NB, class Emit>
+__device__ __forceinline__ void product_emit(const float* w, int ld, const float* bias, int n_out, int c, int g,
+                                             const f4 (&in)[NB][DT], Emit&& emit) {
+  constexpr int KC = DT / KT;
+  static_assert(KC == 1 || KC == 2, "hidden 128 or 256");
+  const int n_tiles = (n_out + 15) >> 4;
+  f4 wa[KT], wb[KT];
+  f4 ba = bias_tile(bias, n_out, 0, g), bn;
+  load_wchunk(w, ld, n_out, 0, 0, c, g, wa);
+  if constexpr (KC == 1) {
+    for (int nt = 0; nt < n_tiles; nt += 2) {
+      bn = bias_tile(bias, n_out, min(nt + 1, n_tiles - 1), g);
+      load_wchunk(w, ld, n_out, min(nt + 1, n_tiles - 1), 0, c, g, wb);
+      PIN_ORDER();
+      {
+        f4 a[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) a[nb] = ba;
+        chunk_product<DT, NB>(wa, 0, in, a);
+        emit(nt, a);
+      }
+      ba = bias_tile(bias, n_out, min(nt + 2, n_tiles - 1), g);
+      load_wchunk(w, ld, n_out, min(nt + 2, n_tiles - 1), 0, c, g, wa);
+      PIN_ORDER();
+      if (nt + 1 < n_tiles) {
+        f4 a[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) a[nb] = bn;
+        chunk_product<DT, NB>(wb, 0, in, a);
+        emit(nt + 1, a);
+      }
+    }
+  } else {
+    for (int nt = 0; nt < n_tiles; ++nt) {
+      load_wchunk(w, ld, n_out, nt, 1, c, g, wb);
+      PIN_ORDER();
+      f4 a[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) a[nb] = ba;
+      chunk_product<DT, NB>(wa, 0, in, a);
+      ba = bias_tile(bias, n_out, min(nt + 1, n_tiles - 1), g);
+      load_wchunk(w, ld, n_out, min(nt + 1, n_tiles - 1), 0, c, g, wa);
+      PIN_ORDER();
+      chunk_product<DT, NB>(wb, 1, in, a);
+      emit(nt, a);
+    }
+  }
+}
+
+#ifndef ACATTN_PROJ_WAVES
+#define ACATTN_PROJ_WAVES 2
+#endif
+template <int H, int NB>
+__global__ void __launch_bounds__(64, ACATTN_PROJ_WAVES) proj_wide_fwd_kernel(const acattn_proj_problem P, const acattn_proj_out O) {
+  constexpr int DT = H / 16;
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const Rows<NB> W = wave_rows<NB>(P.rows);
+  f4 xb[NB][DT], m[NB][DT];
+  load_rows<DT, NB>(P.x, W, g, xb);
+  auto store_tile = [&](float* out, int ld, int n_out, int nt, const f4 (&a)[NB]) {
+    const int j0 = 16 * nt + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (!W.ok[nb]) continue;
+#ifdef ACATTN_PROJ_NOSTORE
+      if (a[nb][0] != 12345.678f) continue;
+#endif
+      float* dst = out + (size_t)W.row[nb] * ld + j0;
+      if (j0 + 3 < n_out) {
+#ifdef ACATTN_PROJ_NT
+        __builtin_nontemporal_store(a[nb], (f4u*)dst);
+#else
+        *(f4u*)dst = a[nb];
+#endif
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j0 + r < n_out) dst[r] = a[nb][r];
+      }
+    }
+  };
+  product_keep<DT, NB, true>(P.wq, P.bq, c, g, xb, m);  // mq
+#ifdef ACATTN_PROJ_NOSTORE
+  if (m[0][0][0] == 12345.678f)
+#endif
+  store_rows<DT, NB>(O.mq, W, g, m);
+  if (O.affine) write_affine<DT, NB>(m, W, P, O.affine, 0, P.b_order[0], P.b_dist[0], 0, c, g);
+  product_emit<DT, NB>(P.waq, H, P.baq, H, c, g, m, [&](int nt, const f4 (&a)[NB]) { store_tile(O.qa, H, H, nt, a); });
+  if (P.wg) {
+    product_emit<DT, NB>(P.wg, H, P.bg, P.G, c, g, m, [&](int nt, const f4 (&a)[NB]) {
+      f4 v[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) v[nb] = O.gate_prob ? gate_value(a[nb], 0) : a[nb];  // sigmoid once for all heads
+      store_tile(O.gate, P.G, P.G, nt, v);
+    });
+  }
+  product_keep<DT, NB, true>(P.wk, P.bk, c, g, xb, m);  // mk
+#ifdef ACATTN_PROJ_NOSTORE
+  if (m[0][0][0] == 12345.678f)
+#endif
+  store_rows<DT, NB>(O.mk, W, g, m);
+  if (O.affine) write_affine<DT, NB>(m, W, P, O.affine, H / P.n_heads, 0.f, 0.f, 2, c, g);
+  product_emit<DT, NB>(P.wak, H, P.bak, H, c, g, m, [&](int nt, const f4 (&a)[NB]) { store_tile(O.ka, H, H, nt, a); });
+  product_emit<DT, NB>(P.wv, H, P.bv, H, c, g, xb, [&](int nt, const f4 (&a)[NB]) { store_tile(O.mv, H, H, nt, a); });
+}
+
+// transposed copies of the layer's weights for the backward: wt[m] = W_m^T as [n_in][ldt], ldt = n_out rounded up to 16
+// (pad columns zero), matrices in the order Wq, Wk, Wv, Waq, Wak ([H, H] each) and Wg ([G, H]) behind them
+struct TransposeJob {
+  const float* src[6];
+  int n_out[6];
+};
+__global__ void __launch_bounds__(256) transpose_weights_kernel(const TransposeJob J, int H, float* ws) {
+  __shared__ float tile[16][17];
+  const int mtx = blockIdx.z;
+  const float* src = J.src[mtx];
+  if (!src) return;
+  const int n_out = J.n_out[mtx], ldt = (n_out + 15) & ~15;
+  size_t off = 0;
+  for (int k = 0; k < mtx; ++k) off += (size_t)H * ((J.n_out[k] + 15) & ~15);
+  float* dst = ws + off;
+  const int o0 = blockIdx.x * 16, i0 = blockIdx.y * 16;
+  if (o0 >= ldt) return;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  tile[ty][tx] = (o0 + ty < n_out) ? src[(size_t)(o0 + ty) * H + i0 + tx] : 0.f;
+  __syncthreads();
+  dst[(size_t)(i0 + ty) * ldt + o0 + tx] = tile[tx][ty];
+}
+
+// dx etc. as in proj_bwd_kernel; wt = the transposed weights above.  Three row-fragment sets fit beside the weight
+// buffers, so the totals are written first and read back (by the lanes that wrote them) as the sources of dx:
+// dmq_total and dmk_total are required outputs here whenever dx is asked for.
+template <int H, int NB, int MODE>
+__global__ void __launch_bounds__(64, 2) proj_wide_bwd_kernel(const acattn_proj_problem P, const acattn_proj_bwd_io IO,
+                                                              const float* __restrict__ wt) {
+  constexpr int DT = H / 16;
+  const bool h_dmq = MODE == 1 || (MODE == 0 && IO.dmq), h_dmk = MODE == 1 || (MODE == 0 && IO.dmk);
+  const bool h_dmv = MODE == 1 || (MODE == 0 && IO.dmv);
+  const bool h_dqa = MODE != 0 || IO.dqa, h_dka = MODE != 0 || IO.dka, h_dx = MODE != 0 || IO.dx;
+  const bool h_qt = MODE != 0 || IO.dmq_total, h_kt = MODE != 0 || IO.dmk_total;
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const Rows<NB> W = wave_rows<NB>(P.rows);
+  const size_t HH = (size_t)H * H;
+  const float *wqT = wt, *wkT = wt + HH, *wvT = wt + 2 * HH, *waqT = wt + 3 * HH, *wakT = wt + 4 * HH, *wgT = wt + 5 * HH;
+  const int ldg = (P.G + 15) & ~15;
+  f4 in[NB][DT], tot[NB][DT];
+  auto zero = [&](f4 (&v)[NB][DT]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) v[nb][t] = f4{0.f, 0.f, 0.f, 0.f};
+  };
+  // ---- d mq (total) = dmq + dqa . Waq + dgate . Wg ------------------------------------------------------------------
+  if (h_dmq) load_rows<DT, NB>(IO.dmq, W, g, tot); else zero(tot);
+  if (h_dqa) {
+    load_rows<DT, NB>(IO.dqa, W, g, in);
+    product_keep<DT, NB, false>(waqT, nullptr, c, g, in, tot);
+  }
+  if (MODE != 2 && IO.dgate && P.wg) {
+    // the contraction runs over the G gate outputs, 16 at a time: B = dgate[row][16 kt + 4 g ..], A = WgT[16 nt + c][16 kt + 4 g ..]
+    const int GT = ldg >> 4;
+    for (int kt = 0; kt < GT; ++kt) {
+      f4 d[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int j0 = 16 * kt + 4 * g;
+        const float* src = IO.dgate + (size_t)W.row[nb] * P.G + j0;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j0 + 3 < P.G) {
+          v = *(const f4u*)src;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j0 + r < P.G) v[r] = src[r];
+        }
+        d[nb] = v;
+      }
+      f4 wg4[DT];
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) wg4[nt] = *(const f4*)(wgT + (size_t)(16 * nt + c) * ldg + 16 * kt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) tot[nb][nt] = mfma16(wg4[nt][r], d[nb][r], tot[nb][nt]);
+    }
+  }
+  if (h_qt) store_rows<DT, NB>(IO.dmq_total, W, g, tot);
+  // ---- d mk (total) = dmk + dka . Wak ---------------------------------------------------------------------------------
+  if (h_dmk) load_rows<DT, NB>(IO.dmk, W, g, tot); else zero(tot);
+  if (h_dka) {
+    load_rows<DT, NB>(IO.dka, W, g, in);
+    product_keep<DT, NB, false>(wakT, nullptr, c, g, in, tot);
+  }
+  if (h_kt) store_rows<DT, NB>(IO.dmk_total, W, g, tot);
+  // ---- dx = dx_init + d mk . Wk + d mq . Wq + d mv . Wv  (tot still holds d mk; d mq comes back from dmq_total) ----------
+  if (h_dx) {
+    f4 (&dx)[NB][DT] = in;
+    if (IO.dx_init) load_rows<DT, NB>(IO.dx_init, W, g, dx); else zero(dx);
+    product_keep<DT, NB, false>(wkT, nullptr, c, g, tot, dx);
+    load_rows<DT, NB>(IO.dmq_total, W, g, tot);
+    product_keep<DT, NB, false>(wqT, nullptr, c, g, tot, dx);
+    if (h_dmv) {
+      load_rows<DT, NB>(IO.dmv, W, g, tot);
+      product_keep<DT, NB, false>(wvT, nullptr, c, g, tot, dx);
+    }
+    store_rows<DT, NB>(IO.dx, W, g, dx);
+  }
+}
+
 int rows_per_wave(int rows) {
   static const int forced = getenv("ACATTN_PROJ_ROWS_PER_WAVE") ? atoi(getenv("ACATTN_PROJ_ROWS_PER_WAVE")) : 0;  // measurements
   if (forced == 16 || forced == 32) return forced;
@@ -391,9 +702,63 @@ int rows_per_wave(int rows) {
 
 }  // namespace
 
-bool acattn_proj_supported(int H, int G) { return H == 64 && G >= 0 && G <= 256; }
+bool acattn_proj_supported(int H, int G) { return (H == 64 || H == 128 || H == 256) && G >= 0 && G <= 256; }
+
+int64_t acattn_proj_bwd_ws_bytes(const acattn_proj_problem& p) {
+  if (p.H == 64) return 0;
+  return ((int64_t)5 * p.H * p.H + (int64_t)p.H * ((p.G + 15) & ~15)) * (int64_t)sizeof(float);
+}
+
+namespace {
+template <int H>
+int launch_wide_fwd(const acattn_proj_problem& p, const acattn_proj_out& o, hipStream_t stream) {
+#ifdef ACATTN_PROJ_NB1
+  constexpr int NB = 1;
+#else
+  constexpr int NB = H == 128 ? 2 : 1;
+#endif
+  const int blocks = (p.rows + 16 * NB - 1) / (16 * NB);
+  hipLaunchKernelGGL((proj_wide_fwd_kernel<H, NB>), dim3(blocks), dim3(64), 0, stream, p, o);
+  return (int)hipGetLastError();
+}
+template <int H>
+int launch_wide_bwd(const acattn_proj_problem& p, const acattn_proj_bwd_io& io, hipStream_t stream) {
+  constexpr int NB = H == 128 ? 2 : 1;
+  if (!io.workspace) {
+    acattn_set_error("projections backward at hidden 128 / 256 needs acattn_proj_bwd_io.workspace");
+    return -1;
+  }
+  if (io.dx && !io.dmq_total) {
+    acattn_set_error("projections backward at hidden 128 / 256: dx needs dmq_total (it is read back as a source of dx)");
+    return -1;
+  }
+  float* wt = (float*)io.workspace;
+  TransposeJob J;
+  const float* src[6] = {p.wq, p.wk, p.wv, p.waq, p.wak, p.wg};
+  for (int k = 0; k < 6; ++k) {
+    J.src[k] = src[k];
+    J.n_out[k] = k < 5 ? p.H : p.G;
+  }
+  const int max_out = std::max(p.H, (p.G + 15) & ~15);
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3(max_out / 16, p.H / 16, p.wg ? 6 : 5), dim3(256), 0, stream, J, p.H, wt);
+  const int blocks = (p.rows + 16 * NB - 1) / (16 * NB);
+  const bool outs = io.dx && io.dmq_total && io.dmk_total, attack = io.dqa && io.dka;
+  const bool all_in = attack && io.dmq && io.dmk && io.dmv && (io.dgate || !p.wg);
+  const bool attack_only = attack && !io.dmq && !io.dmk && !io.dmv && !io.dgate;
+  const int mode = !outs ? 0 : all_in ? 1 : attack_only ? 2 : 0;
+  if (mode == 1)
+    hipLaunchKernelGGL((proj_wide_bwd_kernel<H, NB, 1>), dim3(blocks), dim3(64), 0, stream, p, io, (const float*)wt);
+  else if (mode == 2)
+    hipLaunchKernelGGL((proj_wide_bwd_kernel<H, NB, 2>), dim3(blocks), dim3(64), 0, stream, p, io, (const float*)wt);
+  else
+    hipLaunchKernelGGL((proj_wide_bwd_kernel<H, NB, 0>), dim3(blocks), dim3(64), 0, stream, p, io, (const float*)wt);
+  return (int)hipGetLastError();
+}
+}  // namespace
 
 int acattn_launch_proj_fwd(const acattn_proj_problem& p, const acattn_proj_out& o, hipStream_t stream) {
+  if (p.H == 128) return launch_wide_fwd<128>(p, o, stream);
+  if (p.H == 256) return launch_wide_fwd<256>(p, o, stream);
   const int rpw = rows_per_wave(p.rows), blocks = (p.rows + rpw - 1) / rpw;
   if (rpw == 32)
     hipLaunchKernelGGL((proj_fwd_kernel<64, 2>), dim3(blocks), dim3(64), 0, stream, p, o);
@@ -403,6 +768,8 @@ int acattn_launch_proj_fwd(const acattn_proj_problem& p, const acattn_proj_out& 
 }
 
 int acattn_launch_proj_bwd(const acattn_proj_problem& p, const acattn_proj_bwd_io& io, hipStream_t stream) {
+  if (p.H == 128) return launch_wide_bwd<128>(p, io, stream);
+  if (p.H == 256) return launch_wide_bwd<256>(p, io, stream);
   const int rpw = rows_per_wave(p.rows), blocks = (p.rows + rpw - 1) / rpw;
   const bool outs = io.dx && io.dmq_total && io.dmk_total, attack = io.dqa && io.dka;
   const bool all_in = attack && io.dmq && io.dmk && io.dmv && (io.dgate || !p.wg);

@@ -233,6 +233,9 @@ class _FusedProjections(torch.autograd.Function):
             dx = torch.empty_like(x) if need_dx else None
             io.dmq_total, io.dmk_total, io.dx = _ptr(dmq_t), _ptr(dmk_t), _ptr(dx)
             p = _FusedProjections._problem(x, *params)
+            ws_bytes = int(_lib.load().acattn_projections_bwd_workspace_bytes(C.byref(p)))
+            ws = torch.empty(ws_bytes // 4, device=x.device, dtype=torch.float32) if ws_bytes > 0 else None
+            io.workspace = _ptr(ws)  # transposed weight copies at hidden 128 / 256
             _lib.check(_lib.load().acattn_projections_bwd(C.byref(p), C.byref(io), _stream()), "projections_bwd")
         grads = [None] * 12
         jobs = []

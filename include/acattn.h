@@ -371,7 +371,7 @@ int acattn_select_layer_tail_blocks(int nb);
  *     mq, mk, mv = query(x), key(x), value(x)                               recbole/model/layers.py:687-689
  *     qa, ka     = attack_query_transform(mq), attack_key_transform(mk)     recbole/model/layers.py:658-659
  *     gate       = gate(mq)  [rows, G], G = seq_length                      recbole/model/layers.py:887
- * hidden_size 64, G <= 256; weights are the row-major nn.Linear parameters ([out, in]). */
+ * hidden_size 64, 128 or 256, G <= 256; weights are the row-major nn.Linear parameters ([out, in]). */
 typedef struct acattn_proj_problem {
   int32_t rows, H, G;        /* G = 0 and wg = bg = NULL without the gate (combine_option != 'gate') */
   const float* x;            /* [rows,H] the layer's input */
@@ -408,9 +408,13 @@ typedef struct acattn_proj_bwd_io {
   /* [rows,H] or NULL: dx starts from it.  x also feeds the layer tails as the residual (layers.py:683): their d_x is
    * handed in here instead of being added to dx by a separate elementwise launch. */
   const float* dx_init;
+  /* ABI 26: device scratch of acattn_projections_bwd_workspace_bytes(p) bytes (0 at hidden 64: may be NULL there); hidden
+   * 128 / 256 keep transposed copies of the layer's weights in it for the duration of the launch */
+  void* workspace;
 } acattn_proj_bwd_io;
 
 int acattn_projections_supported(int32_t H, int32_t G);
+int64_t acattn_projections_bwd_workspace_bytes(const acattn_proj_problem* p);
 int acattn_projections_fwd(const acattn_proj_problem* p, const acattn_proj_out* out, void* stream);
 int acattn_projections_bwd(const acattn_proj_problem* p, const acattn_proj_bwd_io* io, void* stream);
 

@@ -96,7 +96,11 @@ def test_validation_errors_without_gpu(lib):
     pp, po = _lib.ProjProblem(), _lib.ProjOut()
     pp.rows, pp.H, pp.G = 16, 64, 300
     assert lib.acattn_projections_fwd(C.byref(pp), C.byref(po), None) < 0 and b"gate" in lib.acattn_last_error()
-    assert lib.acattn_projections_supported(64, 50) == 1 and lib.acattn_projections_supported(128, 50) == 0
+    assert lib.acattn_projections_supported(64, 50) == 1 and lib.acattn_projections_supported(128, 50) == 1
+    assert lib.acattn_projections_supported(256, 200) == 1 and lib.acattn_projections_supported(96, 50) == 0
+    pp.H, pp.G = 128, 100
+    assert lib.acattn_projections_bwd_workspace_bytes(C.byref(pp)) == 4 * (5 * 128 * 128 + 128 * 112)
+    pp.H, pp.G = 64, 300
 
 
 def test_cpu_tensors_fail_loudly(lib):

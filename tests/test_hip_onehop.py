@@ -162,18 +162,19 @@ def test_spatial_affines_entry_point(B, L, H, nh):
     assert (out.cpu() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("B,L,nh", [(32, 50, 2), (5, 37, 4), (512, 50, 2), (3, 200, 1)])
-def test_projections_launch_hands_over_affine_planes_and_gate_probabilities(B, L, nh):
+@pytest.mark.parametrize("B,L,nh,H", [(32, 50, 2, 64), (5, 37, 4, 64), (512, 50, 2, 64), (3, 200, 1, 64),
+                                      (32, 100, 2, 128), (5, 37, 4, 128), (7, 50, 8, 128), (9, 100, 4, 256), (3, 37, 2, 256)])
+def test_projections_launch_hands_over_affine_planes_and_gate_probabilities(B, L, nh, H):
     """acattn_projections_fwd with acattn_proj_out.affine / .gate_prob: the planes from the rows still in its
     accumulators, sigmoid(gate) in place of the logits; everything else and every gradient as without them (the gate
     cotangent that comes back is the gradient of the LOGITS: include/acattn.h)."""
-    H = 64
     g = torch.Generator().manual_seed(B + L)
     r = lambda *s: torch.randn(*s, generator=g)
     t = dict(x=r(B, L, H))
+    ws = 0.2 * (64 / H) ** 0.5
     for n in ("q", "k", "v", "aq", "ak"):
-        t["w" + n], t["b" + n] = 0.2 * r(H, H), 0.1 * r(H)
-    t["wg"], t["bg"] = 0.2 * r(L, H), 0.1 * r(L)
+        t["w" + n], t["b" + n] = ws * r(H, H), 0.1 * r(H)
+    t["wg"], t["bg"] = ws * r(L, H), 0.1 * r(L)
     dh = H // nh
     sp = dict(w_order=0.3 * r(1, 2 * dh), b_order=0.3 * r(1), w_dist=0.3 * r(1, 2 * dh), b_dist=0.3 * r(1))
     W = ("wq", "bq", "wk", "bk", "wv", "bv", "waq", "baq", "wak", "bak", "wg", "bg")

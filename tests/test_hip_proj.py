@@ -26,9 +26,9 @@ def _inputs(rows, H, G, seed):
     r = lambda *s: torch.randn(*s, generator=g)
     t = dict(x=r(rows, H))
     for n in ("q", "k", "v", "aq", "ak"):
-        t["w" + n], t["b" + n] = 0.2 * r(H, H), 0.1 * r(H)
+        t["w" + n], t["b" + n] = 0.2 * (64 / H) ** 0.5 * r(H, H), 0.1 * r(H)
     if G:
-        t["wg"], t["bg"] = 0.2 * r(G, H), 0.1 * r(G)
+        t["wg"], t["bg"] = 0.2 * (64 / H) ** 0.5 * r(G, H), 0.1 * r(G)
     cot = {k: r(rows, G if k == "gate" else H) for k in OUT if (k != "gate" or G)}
     return t, cot
 
@@ -42,9 +42,15 @@ def _reference(t, G):
     return d, out
 
 
-@pytest.mark.parametrize("rows,G", [(512, 50), (37, 50), (16384 + 21, 50), (100, 0), (64, 64), (48, 37), (200, 200), (16400, 130)])
-def test_fused_projections_match_fp64_linears(rows, G):
-    H = 64
+# hidden 128 / 256 [round 3]: the streamed-weight kernels (BASELINE configs[3], [4]); 32 resp. 16 rows per wave, so the
+# ragged row counts end inside a wave's second row block, and G = 200 / 130 / 37 end inside a gate tile
+WIDE = [(512, 50, 128), (37, 50, 128), (16400, 130, 128), (100, 0, 128), (200, 200, 128), (48, 37, 128), (20480 + 17, 100, 128),
+        (512, 50, 256), (37, 0, 256), (4117, 200, 256), (48, 37, 256)]
+
+
+@pytest.mark.parametrize("rows,G,H", [(512, 50, 64), (37, 50, 64), (16384 + 21, 50, 64), (100, 0, 64), (64, 64, 64), (48, 37, 64),
+                                      (200, 200, 64), (16400, 130, 64)] + WIDE)
+def test_fused_projections_match_fp64_linears(rows, G, H):
     t, cot = _inputs(rows, H, G, seed=rows + G)
     d, ref = _reference(t, G)
     loss = sum((ref[k] * cot[k].double()).sum() for k in cot)
@@ -86,8 +92,9 @@ def test_fused_projections_match_fp64_linears(rows, G):
     check(dict(zip(attack_names, gr)), attack_names)
 
 
-def test_fused_projections_equal_library_node():
-    rows, H, G = 25600, 64, 50
+@pytest.mark.parametrize("H", [64, 128, 256])
+def test_fused_projections_equal_library_node(H):
+    rows, G = 25600, 50
     t, cot = _inputs(rows, H, G, seed=3)
     dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
     names = ["x"] + list(W)
@@ -102,11 +109,11 @@ def test_fused_projections_equal_library_node():
         assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, n
 
 
-@pytest.mark.parametrize("rows", [100, 25600])
-def test_residual_gradient_enters_the_backward_launch(rows):
+@pytest.mark.parametrize("rows,H", [(100, 64), (25600, 64), (100, 128), (25600, 128), (1000, 256)])
+def test_residual_gradient_enters_the_backward_launch(rows, H):
     """The node's seventh output is x for the layer's residual connections: a cotangent on it is the start value of dx
     in the backward launch (acattn_proj_bwd_io.dx_init), i.e. dx = dx(projections) + d_res, and alone it passes through."""
-    H, G = 64, 50
+    G = 50
     t, cot = _inputs(rows, H, G, seed=5)
     dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
     res_cot = torch.randn(rows, H, generator=torch.Generator().manual_seed(9)).to(DEV)
