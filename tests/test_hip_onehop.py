@@ -279,3 +279,45 @@ def test_dispatcher_operators_equal_the_direct_c_abi_path():
                            dev["w_order"].reshape(-1), dev["b_order"], dev["w_dist"].reshape(-1), dev["b_dist"], dev["scalar"],
                            nh, p_drop, seed, None, False, None, True),
                           test_utils=("test_schema", "test_faketensor"))
+
+
+@pytest.mark.parametrize("rich", ["fixed", "trainable"])
+@pytest.mark.parametrize("B,L,H,nh,causal", [(3, 100, 64, 2, True), (2, 200, 128, 4, True), (2, 200, 64, 2, False), (3, 130, 64, 4, True)],
+                         ids=["L100", "L200_cfg4_heads", "L200_bidirectional_atomics", "L130_dh16"])
+def test_one_level_backward_beyond_64_matches_oracle_autograd(B, L, H, nh, causal, rich):
+    """two_level = False (recbole/model/layers.py:911-914, 929-936: the origin attention is before_spatial, after_spatial
+    enters through the final mix with ratio 0.5 or the trainable parameter) at L > 64 [round 3: rounds 1-2 built the
+    backward of this variant for L <= 64 only], counter RNG with dropout, against the oracle's autograd."""
+    t, kv, lens, g = _problem(B, L, H, nh, seed=L + nh, causal=causal)
+    seed, p_drop = 99, 0.5
+    rnd = A.materialize_randomness(B, nh, L, seed, p_drop, DEV)
+    names = ["q", "k", "v", "qa", "ka", "gl", "w_order", "b_order", "w_dist", "b_dist", "scalar"]
+    t["rich_ratio"] = torch.tensor([0.37])
+    if rich == "trainable":
+        names.append("rich_ratio")
+    cpu = {k: t[k].clone().requires_grad_(True) for k in names}
+    ocfg = O.EncoderCfg(n_layers=1, n_heads=nh, hidden_size=H, inner_size=4 * H, combine_option="gate", seq_length=L,
+                        attn_dropout_prob=p_drop, two_level=False, rich_calibrated_combine=rich)
+    ref = O.core_from_projected(cpu["q"], cpu["k"], cpu["v"], cpu["qa"], cpu["ka"], cpu["gl"], _oracle_mask(kv, causal),
+                                cpu["w_order"], cpu["b_order"], cpu["w_dist"], cpu["b_dist"], cpu["scalar"], ocfg,
+                                rnd.noise.cpu(), keep_after=rnd.keep_after.cpu().float(), keep_mask=rnd.keep_mask.cpu().float(),
+                                keep_before=rnd.keep_before.cpu().float(), rich_ratio=cpu.get("rich_ratio"))
+    cot = {k: torch.randn(ref[k].shape, generator=g) for k in ("ctx_attacked", "ctx_calibrated", "M")}
+    want = dict(zip(names, torch.autograd.grad(sum((ref[k] * cot[k]).sum() for k in cot), [cpu[k] for k in names])))
+    dev = {k: t[k].to(DEV).requires_grad_(True) for k in names}
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate", two_level=False, rich_calibrated_combine=rich)
+    mask = A.StructuredMask(kv.to(DEV), causal=causal)
+    ctx_a, ctx_c, M, _ = A.calibrated_attention(dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev["gl"], mask, cfg,
+                                                p_drop=p_drop, seed=seed, **{k: dev[k] for k in names[6:]})
+    assert (M.cpu() - ref["M"]).abs().max().item() <= 5e-6
+    assert (ctx_a.cpu() - ref["ctx_attacked"]).abs().max().item() <= 1e-4
+    assert (ctx_c.cpu() - ref["ctx_calibrated"]).abs().max().item() <= 1e-4
+    loss = sum((o * cot[k].to(DEV)).sum() for o, k in ((ctx_a, "ctx_attacked"), (ctx_c, "ctx_calibrated"), (M, "M")))
+    got = dict(zip(names, torch.autograd.grad(loss, [dev[k] for k in names])))
+    bad = []
+    for k in names:
+        scale = want[k].abs().max().item()
+        err = (got[k].cpu() - want[k]).abs().max().item()
+        if err > 2e-3 * scale + 1e-7:
+            bad.append((k, err, scale))
+    assert not bad, bad
