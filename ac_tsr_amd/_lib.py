@@ -108,11 +108,13 @@ class TailProblem(C.Structure):
 
 
 class TailSaved(C.Structure):
-    _fields_ = [("h1", _f), ("st1", _f), ("a", _f), ("act", _f), ("h3", _f), ("st2", _f), ("out", _f)]
+    _fields_ = [("h1", _f), ("st1", _f), ("a", _f), ("act", _f), ("h3", _f), ("st2", _f), ("out", _f),
+                ("gelu_grad", _f)]
 
 
 class TailBwdIO(C.Structure):
-    _fields_ = [("d_out", _f), ("d_ctx", _f), ("d_x", _f), ("d_h1", _f), ("d_h2", _f), ("d_h3", _f), ("dgb_part", _f)]
+    _fields_ = [("d_out", _f), ("d_ctx", _f), ("d_x", _f), ("d_h1", _f), ("d_h2", _f), ("d_h3", _f), ("dgb_part", _f),
+                ("workspace", _f)]
 
 
 class EmbedProblem(C.Structure):
@@ -149,6 +151,8 @@ SYMBOLS = {
     "acattn_layer_tail_fwd": (C.c_int, [C.POINTER(TailProblem), C.POINTER(TailSaved), C.c_void_p]),
     "acattn_layer_tail_bwd": (C.c_int, [C.POINTER(TailProblem), C.POINTER(TailSaved), C.POINTER(TailBwdIO), C.c_void_p]),
     "acattn_layer_tail_bwd_partial_rows": (C.c_int32, [C.c_int32]),
+    "acattn_layer_tail_bwd_partial_rows_for": (C.c_int32, [C.c_int32, C.c_int32]),
+    "acattn_layer_tail_bwd_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "acattn_select_layer_tail_blocks": (C.c_int, [C.c_int]),
     "acattn_adam_step": (C.c_int, [C.POINTER(AdamGroup), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _f,
                                    C.c_void_p]),

@@ -240,7 +240,7 @@ int acattn_projections_bwd(const acattn_proj_problem* p, const acattn_proj_bwd_i
 static int check_tail(const acattn_tail_problem* p, const acattn_tail_saved* s) {
   if (!p || !s) return fail("problem and saved must be non-NULL");
   if (p->rows < 1) return fail("rows must be positive");
-  if (!acattn_tail_supported(p->H, p->I)) return fail("layer tail: (hidden_size, inner_size) must be (64, 256) or (64, 128)");
+  if (!acattn_tail_supported(p->H, p->I)) return fail("layer tail: (hidden_size, inner_size) must be (64, 256), (64, 128), (128, 512) or (128, 256)");
   if (!p->ctx || !p->x || !p->wd || !p->bd || !p->g1 || !p->b1 || !p->w1 || !p->bb1 || !p->w2 || !p->bb2 || !p->g2 || !p->b2)
     return fail("layer tail: inputs and parameters must be non-NULL");
   if (!(p->p1 >= 0.f && p->p1 < 1.f) || !(p->p2 >= 0.f && p->p2 < 1.f)) return fail("dropout probabilities must be in [0, 1)");
@@ -252,6 +252,10 @@ static int check_tail(const acattn_tail_problem* p, const acattn_tail_saved* s) 
 int acattn_layer_tail_supported(int32_t H, int32_t I) { return acattn_tail_supported(H, I) ? 1 : 0; }
 
 int32_t acattn_layer_tail_bwd_partial_rows(int32_t rows) { return acattn_tail_bwd_partial_rows(rows); }
+int32_t acattn_layer_tail_bwd_partial_rows_for(int32_t rows, int32_t H) { return acattn_tail_bwd_partial_rows_h(rows, H); }
+int64_t acattn_layer_tail_bwd_workspace_bytes(int32_t H, int32_t I) {
+  return acattn_tail_supported(H, I) ? acattn_tail_bwd_ws_bytes(H, I) : -1;
+}
 
 int acattn_select_layer_tail_blocks(int nb) {
   if (nb < 0 || nb > 2) return fail("rows per wave: 0 (automatic), 1 or 2 blocks of 16");

@@ -332,6 +332,8 @@ int acattn_launch_proj_fwd(const acattn_proj_problem& p, const acattn_proj_out& 
 int acattn_launch_proj_bwd(const acattn_proj_problem& p, const acattn_proj_bwd_io& io, hipStream_t stream);
 bool acattn_tail_supported(int H, int I);
 int acattn_tail_bwd_partial_rows(int rows);
+int acattn_tail_bwd_partial_rows_h(int rows, int H);
+int64_t acattn_tail_bwd_ws_bytes(int H, int I);
 int acattn_select_tail_nb(int nb);
 int acattn_launch_tail_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream);
 int acattn_launch_tail_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const acattn_tail_bwd_io& io,

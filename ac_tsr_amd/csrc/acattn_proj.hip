@@ -413,6 +413,12 @@ __device__ __forceinline__ void load_wchunk(const float* w, int ld, int n_out, i
 #ifdef ACATTN_PROJ_W0
   nt = 0;
 #endif
+#ifdef ACATTN_PROJ_COALESCED  // timing only: what a pre-swizzled weight layout (one contiguous KB per wave load) would cost
+  const int ntc = min(nt, (n_out >> 4) - 1), lane = 16 * g + c, dt = ld / 16;
+#pragma unroll
+  for (int t = 0; t < KT; ++t) frag[t] = *(const f4*)(w + ((size_t)(ntc * dt + KT * kc + t) * 64 + lane) * 4);
+  return;
+#endif
   const int o = min(16 * nt + c, n_out - 1);
 #pragma unroll
   for (int t = 0; t < KT; ++t) frag[t] = *(const f4*)(w + (size_t)o * ld + 16 * (KT * kc + t) + 4 * g);

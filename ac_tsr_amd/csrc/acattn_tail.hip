@@ -42,6 +42,7 @@
 #include "acattn_rowops.h"
 
 int acattn_tail_bwd_partial_rows(int rows);
+int acattn_tail_bwd_partial_rows_h(int rows, int H);
 
 namespace {
 
@@ -51,6 +52,8 @@ bool split_slabs(int rows) {
   static const int limit = getenv("ACATTN_TAIL_SPLIT_ROWS") ? atoi(getenv("ACATTN_TAIL_SPLIT_ROWS")) : 4096;
   return g_tail_nb == 0 && rows <= limit;
 }
+// hidden 128 / 256: one row block per wave; four waves per block below this many rows
+bool wide_split(int rows) { return rows <= 8192; }
 int rows_per_wave(int rows) { return split_slabs(rows) ? 16 : 16 * (g_tail_nb ? g_tail_nb : (rows >= 16384 ? 2 : 1)); }
 
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
@@ -130,6 +133,29 @@ __device__ __forceinline__ void ln_forward(const f4 (&z)[DT], const f4 (&res)[DT
   rstd = __builtin_amdgcn_rsqf(quad_sum(sq) * inv_h + eps);
 #pragma unroll
   for (int t = 0; t < DT; ++t) y[t] = (s[t] * rstd) * gamma[t] + beta[t];
+}
+
+// the same with gamma / beta read where they are used (hidden 128 / 256: no registers to park them in)
+template <int DT>
+__device__ __forceinline__ void ln_forward_mem(const f4 (&z)[DT], const f4 (&res)[DT], const f4 (&keep)[DT], const float* gamma,
+                                               const float* beta, int g, float eps, f4 (&y)[DT], float& mean, float& rstd) {
+  constexpr float inv_h = 1.0f / (16 * DT);
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    y[t] = z[t] * keep[t] + res[t];
+    sum += (y[t][0] + y[t][1]) + (y[t][2] + y[t][3]);
+  }
+  mean = quad_sum(sum) * inv_h;
+  float sq = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    y[t] = y[t] - mean;
+    sq += (y[t][0] * y[t][0] + y[t][1] * y[t][1]) + (y[t][2] * y[t][2] + y[t][3] * y[t][3]);
+  }
+  rstd = __builtin_amdgcn_rsqf(quad_sum(sq) * inv_h + eps);
+#pragma unroll
+  for (int t = 0; t < DT; ++t) y[t] = (y[t] * rstd) * *(const f4*)(gamma + 16 * t + 4 * g) + *(const f4*)(beta + 16 * t + 4 * g);
 }
 
 template <int DT>
@@ -522,6 +548,375 @@ __global__ void __launch_bounds__(64 * NW) tail_bwd_kernel(const acattn_tail_pro
 }
 
 
+// =====================================================================================================================
+// Hidden 128 / 256 (BASELINE configs[3], [4]) [round 3].  The kernels above keep the dense weights ([H, H] as MFMA
+// fragments: (H/16)^2 float4 per lane) and three slabs of the feed-forward weights in registers; at H = 128 that is 256 +
+// 204 registers.  Here every weight STREAMS, one 16-row tile / one inner slab at a time, each requested one MFMA group
+// (32-64 instructions) before its use and two waves per SIMD covering the rest of the latency; one wave owns 16 rows
+// (NB = 1), the LayerNorm parameters are read where they are used.  The backward reads TRANSPOSED copies of the three
+// weight matrices from a caller workspace (acattn_tail_bwd_io.workspace, filled by tail_transpose_kernel in front of
+// it): 16-byte fragment loads instead of 64 dword gathers per slab.
+// ---------------------------------------------------------------------------------------------------------------------
+// out tile nt of  W[n_out = 16 DT][16 DT] . in^T  (+ bias), tiles emitted in order; weights one tile ahead
+template <int DT, class Emit>
+__device__ __forceinline__ void stream_square(const float* w, const float* bias, int c, int g, const f4 (&in)[DT], Emit&& emit) {
+  constexpr int H = 16 * DT;
+  f4 wbuf[2][DT], bb[2];
+  auto load = [&](int nt, f4 (&dst)[DT], f4& b) {
+    b = bias ? *(const f4*)(bias + 16 * nt + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dst[t] = *(const f4*)(w + (size_t)(16 * nt + c) * H + 16 * t + 4 * g);
+  };
+  load(0, wbuf[0], bb[0]);
+  static_for<DT>([&](auto k) {
+    constexpr int NT = decltype(k)::value;
+    if constexpr (NT + 1 < DT) load(NT + 1, wbuf[(NT + 1) & 1], bb[(NT + 1) & 1]);
+    PIN_ORDER();
+    f4 acc[2] = {bb[NT & 1], f4{0.f, 0.f, 0.f, 0.f}};  // two partial accumulators (see first_product above)
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r & 1] = mfma16(wbuf[NT & 1][t][r], in[t][r], acc[r & 1]);
+    emit(k, acc[0] + acc[1]);
+  });
+}
+
+template <int H, int I, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) tail_wide_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
+  constexpr int DT = H / 16, IT = I / 16, NS = IT / NW;
+  static_assert(NS >= 2, "two slabs are requested ahead");
+  const int c = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+  const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const Rows<1> W = wave_rows<1>(P);
+  const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
+  const int row = W.row[0];
+  const bool ok = W.ok[0];
+
+  // ---- h1 = dense(ctx) + bias;  a = LayerNorm(dropout(h1) + x) ---------------------------------------------------------
+  f4 a[DT];
+  {
+    f4 cb[DT], res[DT], h1[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      cb[t] = *(const f4*)(P.ctx + (size_t)W.src[0] * H + 16 * t + 4 * g);
+      res[t] = *(const f4*)(P.x + (size_t)W.src[0] * H + 16 * t + 4 * g);
+    }
+    stream_square<DT>(P.wd, P.bd, c, g, cb, [&](auto k, f4 v) { h1[decltype(k)::value] = v; });
+    f4 keep[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, row, 4 * t + g, H);
+    float mean, rstd;
+    ln_forward_mem<DT>(h1, res, keep, P.g1, P.b1, g, P.eps1, a, mean, rstd);
+    if (ok && wave == 0) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)row * H + 16 * t + 4 * g;
+        *(f4*)(S.h1 + o) = h1[t];
+        *(f4*)(S.a + o) = a[t];
+      }
+      if (g == 0) *(float2*)(S.st1 + 2 * (size_t)row) = float2{mean, rstd};
+    }
+  }
+
+  // ---- h3 = dense_2(gelu(dense_1(a))), one inner slab (16 columns) at a time ------------------------------------------------
+  // slab j of this wave = inner tile mt = wave + NW j.  Step j: request w1 of slab j + 2 (its buffer was released by the
+  // first product of slab j, done in step j - 1); first product of slab j + 1 next to the GELU of slab j; second product
+  // of slab j; request w2 of slab j + 1 into the ONE w2 buffer (a second one does not fit under 256 registers: its lead
+  // is the next step's first product, the SIMD's other wave covers the rest).
+  f4 w1b[2][DT], w2b[DT], b1b[3];
+  auto load_w1 = [&](int mt, f4 (&dst)[DT], f4& b) {
+    b = *(const f4*)(P.bb1 + 16 * mt + 4 * g);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dst[t] = *(const f4*)(P.w1 + (size_t)(16 * mt + c) * H + 16 * t + 4 * g);
+  };
+  auto load_w2 = [&](int mt, f4 (&dst)[DT]) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dst[t] = *(const f4*)(P.w2 + (size_t)(16 * t + c) * I + 16 * mt + 4 * g);
+  };
+  load_w1(wave, w1b[0], b1b[0]);
+  load_w1(wave + NW, w1b[1], b1b[1]);
+  load_w2(wave, w2b);
+  f4 h3[DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt) h3[nt] = wave == 0 ? *(const f4*)(P.bb2 + 16 * nt + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
+  PIN_ORDER();
+  auto first_product = [&](const f4 (&w1)[DT], f4 (&h2)[2]) {
+    h2[0] = h2[1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h2[r & 1] = mfma16(w1[t][r], a[t][r], h2[r & 1]);
+  };
+  f4 h2[2][2];
+  first_product(w1b[0], h2[0]);
+  static_for<NS>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    const int mt = wave + NW * J;
+    if constexpr (J + 2 < NS) load_w1(mt + 2 * NW, w1b[J & 1], b1b[(J + 2) % 3]);
+    PIN_ORDER();
+    if constexpr (J + 1 < NS) first_product(w1b[(J + 1) & 1], h2[(J + 1) & 1]);
+    const f4 pre = (h2[J & 1][0] + h2[J & 1][1]) + b1b[J % 3];
+    f4 act, dact;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const PhiExp pe = phi_exp(pre[r]);
+      act[r] = pre[r] * pe.phi;
+      dact[r] = fmaf(pre[r] * kInvSqrt2Pi, pe.e, pe.phi);
+    }
+    if (ok) {
+      *(f4*)(S.act + (size_t)row * I + 16 * mt + 4 * g) = act;
+      // gelu'(h2): at this width rebuilding h2 in the backward is a fourth of its matrix work, 2 x 4 I bytes per row are not
+      if (S.gelu_grad) *(f4*)(S.gelu_grad + (size_t)row * I + 16 * mt + 4 * g) = dact;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) h3[nt] = mfma16(w2b[nt][r], act[r], h3[nt]);
+    PIN_ORDER();
+    if constexpr (J + 1 < NS) load_w2(mt + NW, w2b);
+  });
+
+  if (NW > 1) {  // fold the waves' partial products into wave 0
+    __shared__ f4 red[NW > 1 ? NW - 1 : 1][DT][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) red[wave - 1][t][threadIdx.x & 63] = h3[t];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) h3[t] += red[w][t][threadIdx.x & 63];
+  }
+
+  // ---- out = LayerNorm(dropout(h3) + a) -------------------------------------------------------------------------
+  {
+    f4 keep[DT], y[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) keep[t] = row_keep_scale(P.p2, P.keep2, P.seed2 + step, row, 4 * t + g, H);
+    float mean, rstd;
+    ln_forward_mem<DT>(h3, a, keep, P.g2, P.b2, g, P.eps2, y, mean, rstd);
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)row * H + 16 * t + 4 * g;
+        *(f4*)(S.h3 + o) = h3[t];
+        *(f4*)(S.out + o) = y[t];
+      }
+      if (g == 0) *(float2*)(S.st2 + 2 * (size_t)row) = float2{mean, rstd};
+    }
+  }
+}
+
+// transposed copies for the wide backward: ws = [ W1^T [H][I] | W2^T [I][H] | Wd^T [H][H] ]
+__global__ void __launch_bounds__(256) tail_transpose_kernel(const float* w1, const float* w2, const float* wd, int H, int I, float* ws) {
+  __shared__ float tile[16][17];
+  const int mtx = blockIdx.z;
+  const float* src = mtx == 0 ? w1 : mtx == 1 ? w2 : wd;
+  const int R = mtx == 0 ? I : H, Cn = mtx == 1 ? I : H;  // src is [R][Cn], dst [Cn][R]
+  float* dst = ws + (mtx == 0 ? 0 : mtx == 1 ? (size_t)H * I : 2 * (size_t)H * I);
+  const int r0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+  if (r0 >= R || c0 >= Cn) return;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  tile[ty][tx] = src[(size_t)(r0 + ty) * Cn + c0 + tx];
+  __syncthreads();
+  dst[(size_t)(c0 + ty) * R + r0 + tx] = tile[tx][ty];
+}
+
+// LayerNorm backward of one row block without the two accumulator arrays of ln_backward (one row block per wave: the
+// partial sums of dgamma / dbeta are the block's own): the normalised value is formed twice instead of being kept
+template <int DT>
+__device__ __forceinline__ void ln_backward_wide(const f4 (&z)[DT], const f4 (&res)[DT], const f4 (&keep)[DT], const float* gamma,
+                                                 float mean, float rstd, const f4 (&dy)[DT], bool ok, bool write_part, int c, int g,
+                                                 f4 (&dz)[DT], float* part_g, float* part_b) {
+  constexpr float inv_h = 1.0f / (16 * DT);
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    const f4 xh = ((z[t] * keep[t] + res[t]) - mean) * rstd;
+    const f4 gg = dy[t] * *(const f4*)(gamma + 16 * t + 4 * g);
+    m1 += (gg[0] + gg[1]) + (gg[2] + gg[3]);
+    m2 += (gg[0] * xh[0] + gg[1] * xh[1]) + (gg[2] * xh[2] + gg[3] * xh[3]);
+    if (part_g) {
+      f4 pg, pb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pg[r] = dpp_row_sum(ok ? dy[t][r] * xh[r] : 0.f);  // over the 16 rows of the lane group
+        pb[r] = dpp_row_sum(ok ? dy[t][r] : 0.f);
+      }
+      if (c == 0 && write_part) {
+        *(f4*)(part_g + 16 * t + 4 * g) = pg;
+        *(f4*)(part_b + 16 * t + 4 * g) = pb;
+      }
+    }
+  }
+  m1 = quad_sum(m1) * inv_h;
+  m2 = quad_sum(m2) * inv_h;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    const f4 xh = ((z[t] * keep[t] + res[t]) - mean) * rstd;
+    const f4 gg = dy[t] * *(const f4*)(gamma + 16 * t + 4 * g);
+    dz[t] = (gg - m1 - xh * m2) * rstd;
+  }
+}
+
+// SAVED: gelu'(h2) comes from acattn_tail_saved.gelu_grad instead of a rebuilt h2
+template <int H, int I, int NW, bool SAVED>
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) tail_wide_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
+                                                                                 const acattn_tail_bwd_io IO, const float* __restrict__ ws) {
+  constexpr int DT = H / 16, IT = I / 16;
+  const int c = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+  const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const Rows<1> W = wave_rows<1>(P);
+  const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
+  const int row = W.row[0];
+  const bool ok = W.ok[0];
+  float* part = IO.dgb_part ? IO.dgb_part + (size_t)blockIdx.x * 4 * H : nullptr;
+  const float *w1T = ws, *w2T = ws + (size_t)H * I, *wdT = ws + 2 * (size_t)H * I;
+
+  // ---- through the second LayerNorm: d h3 (after the dropout), d a (residual share) -------------------------------
+  f4 a[DT], dh3[DT], da[DT];
+  {
+    f4 z[DT], keep[DT], dy[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const size_t o = (size_t)row * H + 16 * t + 4 * g;
+      z[t] = *(const f4*)(S.h3 + o);
+      a[t] = *(const f4*)(S.a + o);
+      dy[t] = *(const f4*)(IO.d_out + o);
+      keep[t] = row_keep_scale(P.p2, P.keep2, P.seed2 + step, row, 4 * t + g, H);
+    }
+    const float2 st = *(const float2*)(S.st2 + 2 * (size_t)row);
+    ln_backward_wide<DT>(z, a, keep, P.g2, st.x, st.y, dy, ok, wave == 0, c, g, da, part ? part + 2 * H : nullptr,
+                         part ? part + 3 * H : nullptr);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      dh3[t] = da[t] * keep[t];
+      if (IO.d_h3 && ok && wave == 0) *(f4*)(IO.d_h3 + (size_t)row * H + 16 * t + 4 * g) = dh3[t];
+      if (wave > 0) da[t] = f4{0.f, 0.f, 0.f, 0.f};  // the residual share of d a travels with wave 0
+    }
+  }
+
+  // ---- d a += W1^T (gelu'(h2) * (W2^T d h3)), slab by slab; h2 rebuilt from a --------------------------------------
+  // per slab: [request W1^T fragments] [h2 and d act: 2 x 4 DT MFMAs] [request the next slab's W1 / W2^T] [GELU'] [d a: 4 DT]
+  {
+    f4 w1[SAVED ? 1 : DT], w2t[DT], w1t[DT], b1;  // (b1: the bias of the slab, or its saved gelu')
+    auto load_pair = [&](int mt) {
+      b1 = SAVED ? *(const f4*)(S.gelu_grad + (size_t)row * I + 16 * mt + 4 * g) : *(const f4*)(P.bb1 + 16 * mt + 4 * g);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        if constexpr (!SAVED) w1[t] = *(const f4*)(P.w1 + (size_t)(16 * mt + c) * H + 16 * t + 4 * g);  // A[m = 16mt+c][k = 16t+4g+r]
+        w2t[t] = *(const f4*)(w2T + (size_t)(16 * mt + c) * H + 16 * t + 4 * g);   // A[m = 16mt+c][n = 16t+4g+r] = W2[n][m]
+      }
+    };
+    load_pair(wave);
+    for (int mt = wave; mt < IT; mt += NW) {
+#pragma unroll
+      for (int nt = 0; nt < DT; ++nt) w1t[nt] = *(const f4*)(w1T + (size_t)(16 * nt + c) * I + 16 * mt + 4 * g);  // A[k][m] = W1[m][k]
+      PIN_ORDER();
+      f4 h2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, dact[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (!SAVED) h2[r & 1] = mfma16(w1[t][r], a[t][r], h2[r & 1]);
+          dact[r & 1] = mfma16(w2t[t][r], dh3[t][r], dact[r & 1]);
+        }
+      const f4 pre = (h2[0] + h2[1]) + b1, dac = dact[0] + dact[1];
+      PIN_ORDER();
+      load_pair(mt + NW < IT ? mt + NW : mt);
+      PIN_ORDER();
+      f4 dh2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh2[r] = dac[r] * (SAVED ? pre[r] : gelu_erf_grad(pre[r]));
+      if (IO.d_h2 && ok) *(f4*)(IO.d_h2 + (size_t)row * I + 16 * mt + 4 * g) = dh2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt) da[nt] = mfma16(w1t[nt][r], dh2[r], da[nt]);
+    }
+  }
+
+  if (NW > 1) {  // fold the waves' shares of d a into wave 0
+    __shared__ f4 red[NW > 1 ? NW - 1 : 1][DT][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) red[wave - 1][t][threadIdx.x & 63] = da[t];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) da[t] += red[w][t][threadIdx.x & 63];
+  }
+
+  // ---- through the first LayerNorm: d h1, d x; then d ctx = d h1 . Wd ---------------------------------------------
+  f4 dh1[DT];
+  {
+    f4 z[DT], res[DT], keep[DT], dz[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const size_t o = (size_t)row * H + 16 * t + 4 * g;
+      z[t] = *(const f4*)(S.h1 + o);
+      res[t] = *(const f4*)(P.x + (size_t)W.src[0] * H + 16 * t + 4 * g);
+      keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, row, 4 * t + g, H);
+    }
+    const float2 st = *(const float2*)(S.st1 + 2 * (size_t)row);
+    ln_backward_wide<DT>(z, res, keep, P.g1, st.x, st.y, da, ok, true, c, g, dz, part, part ? part + H : nullptr);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const size_t o = (size_t)row * H + 16 * t + 4 * g;
+      dh1[t] = dz[t] * keep[t];
+      if (ok) {
+        if (IO.d_x) store_grad(IO.d_x + (size_t)W.src[0] * H + 16 * t + 4 * g, dz[t], P.src_index != nullptr);
+        if (IO.d_h1) *(f4*)(IO.d_h1 + o) = dh1[t];
+      }
+    }
+  }
+  if (IO.d_ctx) {
+    // dense^T: A[k = 16nt+c][n = 16t+4g+r] = Wd[n][k] = WdT[16nt+c][16t+4g+r]
+    stream_square<DT>(wdT, nullptr, c, g, dh1, [&](auto k, f4 v) {
+      if (ok) store_grad(IO.d_ctx + (size_t)W.src[0] * H + 16 * decltype(k)::value + 4 * g, v, P.src_index != nullptr);
+    });
+  }
+}
+
+template <int H, int I>
+int launch_wide_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
+  const int blocks = (p.rows + 15) / 16;
+  if (wide_split(p.rows))
+    hipLaunchKernelGGL((tail_wide_fwd_kernel<H, I, 4>), dim3(blocks), dim3(256), 0, stream, p, s);
+  else
+    hipLaunchKernelGGL((tail_wide_fwd_kernel<H, I, 1>), dim3(blocks), dim3(64), 0, stream, p, s);
+  return (int)hipGetLastError();
+}
+
+template <int H, int I>
+int launch_wide_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const acattn_tail_bwd_io& io, hipStream_t stream) {
+  if (!io.workspace) {
+    acattn_set_error("layer tail backward at hidden 128 / 256 needs acattn_tail_bwd_io.workspace");
+    return -1;
+  }
+  float* ws = (float*)io.workspace;
+  hipLaunchKernelGGL(tail_transpose_kernel, dim3(I / 16, I / 16, 3), dim3(256), 0, stream, p.w1, p.w2, p.wd, H, I, ws);
+  const int blocks = (p.rows + 15) / 16;
+  const bool split = wide_split(p.rows);
+  if (s.gelu_grad) {
+    if (split)
+      hipLaunchKernelGGL((tail_wide_bwd_kernel<H, I, 4, true>), dim3(blocks), dim3(256), 0, stream, p, s, io, (const float*)ws);
+    else
+      hipLaunchKernelGGL((tail_wide_bwd_kernel<H, I, 1, true>), dim3(blocks), dim3(64), 0, stream, p, s, io, (const float*)ws);
+  } else {
+    if (split)
+      hipLaunchKernelGGL((tail_wide_bwd_kernel<H, I, 4, false>), dim3(blocks), dim3(256), 0, stream, p, s, io, (const float*)ws);
+    else
+      hipLaunchKernelGGL((tail_wide_bwd_kernel<H, I, 1, false>), dim3(blocks), dim3(64), 0, stream, p, s, io, (const float*)ws);
+  }
+  return (int)hipGetLastError();
+}
+
 template <int H, int I>
 int launch_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
   const int nb = rows_per_wave(p.rows) / 16;
@@ -554,9 +949,13 @@ int launch_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const a
 
 }  // namespace
 
-bool acattn_tail_supported(int H, int I) { return H == 64 && (I == 256 || I == 128); }
+bool acattn_tail_supported(int H, int I) {
+  return (H == 64 && (I == 256 || I == 128)) || (H == 128 && (I == 512 || I == 256));
+}
 
 int acattn_tail_bwd_partial_rows(int rows) { return (rows + rows_per_wave(rows) - 1) / rows_per_wave(rows); }
+int acattn_tail_bwd_partial_rows_h(int rows, int H) { return H > 64 ? (rows + 15) / 16 : acattn_tail_bwd_partial_rows(rows); }
+int64_t acattn_tail_bwd_ws_bytes(int H, int I) { return H > 64 ? ((int64_t)2 * H * I + (int64_t)H * H) * (int64_t)sizeof(float) : 0; }
 
 int acattn_select_tail_nb(int nb) {
   const int prev = g_tail_nb;
@@ -567,6 +966,8 @@ int acattn_select_tail_nb(int nb) {
 int acattn_launch_tail_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
   if (p.H == 64 && p.I == 256) return launch_fwd<64, 256>(p, s, stream);
   if (p.H == 64 && p.I == 128) return launch_fwd<64, 128>(p, s, stream);
+  if (p.H == 128 && p.I == 512) return launch_wide_fwd<128, 512>(p, s, stream);
+  if (p.H == 128 && p.I == 256) return launch_wide_fwd<128, 256>(p, s, stream);
   acattn_set_error("layer tail: unsupported (hidden_size, inner_size)");
   return -1;
 }
@@ -575,6 +976,8 @@ int acattn_launch_tail_bwd(const acattn_tail_problem& p, const acattn_tail_saved
                            hipStream_t stream) {
   if (p.H == 64 && p.I == 256) return launch_bwd<64, 256>(p, s, io, stream);
   if (p.H == 64 && p.I == 128) return launch_bwd<64, 128>(p, s, io, stream);
+  if (p.H == 128 && p.I == 512) return launch_wide_bwd<128, 512>(p, s, io, stream);
+  if (p.H == 128 && p.I == 256) return launch_wide_bwd<128, 256>(p, s, io, stream);
   acattn_set_error("layer tail: unsupported (hidden_size, inner_size)");
   return -1;
 }

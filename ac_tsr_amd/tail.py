@@ -70,14 +70,17 @@ class _FusedLayerTail(torch.autograd.Function):
         new = lambda *shape: torch.empty(*shape, device=c.device, dtype=torch.float32)
         h1, a, h3, out = (new(*out_shape) for _ in range(4))
         st1, st2, act = new(rows, 2), new(rows, 2), new(rows, I)
+        # hidden 128: gelu'(dense_1(a)) is saved as well (the backward would spend a fourth of its matrix work rebuilding it)
+        dgelu = new(rows, I) if (H > 64 and any(ctx.needs_input_grad)) else None
         p = _tail_problem(c, x, *params, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_tensor, pick)
         sv = _lib.TailSaved()
         sv.h1, sv.st1, sv.a, sv.act, sv.h3, sv.st2, sv.out = (_ptr(t) for t in (h1, st1, a, act, h3, st2, out))
+        sv.gelu_grad = _ptr(dgelu)
         _lib.check(_lib.load().acattn_layer_tail_fwd(C.byref(p), C.byref(sv), _stream()), "layer_tail_fwd")
         empty = c.new_empty(0)
         ctx.save_for_backward(c, x, h1, st1, a, act, h3, st2, *params, k1 if k1 is not None else empty,
                               k2 if k2 is not None else empty, seed_tensor if seed_tensor is not None else empty,
-                              pick if pick is not None else empty)
+                              pick if pick is not None else empty, dgelu if dgelu is not None else empty)
         ctx.args = (eps1, eps2, p1, p2, k1 is not None, k2 is not None, seed1, seed2, seed_tensor is not None,
                     pick is not None)
         return out
@@ -86,7 +89,7 @@ class _FusedLayerTail(torch.autograd.Function):
     def backward(ctx, d_out):
         c, x, h1, st1, a, act, h3, st2 = ctx.saved_tensors[:8]
         params = ctx.saved_tensors[8:18]
-        k1, k2, seed_t, pick = ctx.saved_tensors[18:]
+        k1, k2, seed_t, pick, dgelu = ctx.saved_tensors[18:]
         eps1, eps2, p1, p2, has_k1, has_k2, seed1, seed2, has_seed_t, has_pick = ctx.args
         k1, k2, seed_t = (k1 if has_k1 else None), (k2 if has_k2 else None), (seed_t if has_seed_t else None)
         pick = pick if has_pick else None
@@ -99,6 +102,7 @@ class _FusedLayerTail(torch.autograd.Function):
         p = _tail_problem(c, x, *params, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_t, pick)
         sv = _lib.TailSaved()
         sv.h1, sv.st1, sv.a, sv.act, sv.h3, sv.st2 = (_ptr(t) for t in (h1, st1, a, act, h3, st2))
+        sv.gelu_grad = _ptr(dgelu) if dgelu.numel() else None
         io = _lib.TailBwdIO()
         # with a row selection the kernel writes the picked positions only: the rest of the gradient is zero
         if pick is not None and need_c and need_x:
@@ -111,8 +115,11 @@ class _FusedLayerTail(torch.autograd.Function):
         d_h1 = d_h2 = d_h3 = part = None
         if want_params:
             d_h1, d_h2, d_h3 = new(rows, H), new(rows, I), new(rows, H)
-            part = new(int(lib.acattn_layer_tail_bwd_partial_rows(rows)), 4 * H)
+            part = new(int(lib.acattn_layer_tail_bwd_partial_rows_for(rows, H)), 4 * H)
             io.d_h1, io.d_h2, io.d_h3, io.dgb_part = _ptr(d_h1), _ptr(d_h2), _ptr(d_h3), _ptr(part)
+        ws_bytes = int(lib.acattn_layer_tail_bwd_workspace_bytes(H, I))
+        ws = new(ws_bytes // 4) if ws_bytes > 0 else None  # transposed weight copies at hidden 128
+        io.workspace = _ptr(ws)
         _lib.check(lib.acattn_layer_tail_bwd(C.byref(p), C.byref(sv), C.byref(io), _stream()), "layer_tail_bwd")
         grads = [None] * 10  # wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2
         if want_params:

@@ -345,6 +345,10 @@ typedef struct acattn_tail_saved {
   float* h3;   /* [rows,H] dense_2(act) + bias */
   float* st2;  /* [rows,2] */
   float* out;  /* [rows,H] the branch's output */
+  /* ABI 26, optional (NULL = off), hidden 128 only: [rows,I] gelu'(dense_1(a)).  When the forward is given it, the
+   * backward given the same pointer reads it instead of rebuilding dense_1(a) (a fourth of its matrix work at that
+   * width).  Ignored at hidden 64 (the rebuild is cheaper than the traffic there). */
+  float* gelu_grad;
 } acattn_tail_saved;
 
 typedef struct acattn_tail_bwd_io {
@@ -355,14 +359,19 @@ typedef struct acattn_tail_bwd_io {
   float* d_h2;         /*   operands of acattn_linear_wgrad_grouped with (ctx, a, act); each may be NULL */
   float* d_h3;
   float* dgb_part;     /* [acattn_layer_tail_bwd_partial_rows(rows), 4, H] partial sums of (dgamma1, dbeta1, dgamma2,
-                          dbeta2), to be summed over the leading dimension by the caller; or NULL */
+                          dbeta2), to be summed over the leading dimension by the caller; or NULL.  Hidden 128 / 256:
+                          acattn_layer_tail_bwd_partial_rows_for(rows, H) rows */
+  void* workspace;     /* ABI 26: device scratch of acattn_layer_tail_bwd_workspace_bytes(H, I) bytes (0 at hidden 64: may
+                          be NULL there); hidden 128 / 256 keep transposed weight copies in it during the launch */
 } acattn_tail_bwd_io;
 
 int acattn_layer_tail_supported(int32_t H, int32_t I);
 int acattn_layer_tail_fwd(const acattn_tail_problem* p, const acattn_tail_saved* saved, void* stream);
 int acattn_layer_tail_bwd(const acattn_tail_problem* p, const acattn_tail_saved* saved, const acattn_tail_bwd_io* io,
                           void* stream);
-int32_t acattn_layer_tail_bwd_partial_rows(int32_t rows);
+int32_t acattn_layer_tail_bwd_partial_rows(int32_t rows);               /* hidden 64 */
+int32_t acattn_layer_tail_bwd_partial_rows_for(int32_t rows, int32_t H); /* any supported hidden size */
+int64_t acattn_layer_tail_bwd_workspace_bytes(int32_t H, int32_t I);
 /* Measurement hook: rows per wave of the forward = 16 * nb (0 = chosen by size).  Returns the previous setting. */
 int acattn_select_layer_tail_blocks(int nb);
 

@@ -21,6 +21,7 @@ NAMES = ("c", "x", "wd", "bd", "g1", "b1", "w1", "bb1", "w2", "bb2", "g2", "b2")
 
 
 def _inputs(rows, H, I, seed, scale=0.3):
+    scale = scale * (64 / H) ** 0.5  # keeps the products O(1) at every width
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g)
     return dict(c=r(rows, H), x=r(rows, H), wd=scale * r(H, H), bd=0.1 * r(H), g1=1 + 0.3 * r(H), b1=0.3 * r(H),
@@ -41,10 +42,13 @@ def _apply(node, dev, eps, p, keep1, keep2, seed1, seed2, state):
     return node.apply(*(dev[k] for k in NAMES), eps, eps, p, p, keep1, keep2, seed1, seed2, None, state)
 
 
-@pytest.mark.parametrize("rows,I", [(512, 256), (37, 256), (16384 + 21, 256), (100, 128)])
+# hidden 128 [round 3]: the streamed-weight kernels (BASELINE configs[3]: H = 128, inner 512); four waves per row block
+# up to 8192 rows, one above
+@pytest.mark.parametrize("rows,I,H", [(512, 256, 64), (37, 256, 64), (16384 + 21, 256, 64), (100, 128, 64),
+                                      (512, 512, 128), (37, 512, 128), (8192 + 21, 512, 128), (100, 256, 128), (20000, 256, 128)])
 @pytest.mark.parametrize("p", [0.0, 0.5])
-def test_fused_tail_matches_fp64_chain(rows, I, p):
-    H, eps = 64, 1e-12
+def test_fused_tail_matches_fp64_chain(rows, I, p, H):
+    eps = 1e-12
     t, g = _inputs(rows, H, I, seed=rows + I)
     keep1 = torch.empty(rows, H).bernoulli_(1 - p, generator=g) if p > 0 else None
     keep2 = torch.empty(rows, H).bernoulli_(1 - p, generator=g) if p > 0 else None
@@ -67,11 +71,11 @@ def test_fused_tail_matches_fp64_chain(rows, I, p):
     assert torch.equal(gc, got[0]) and torch.equal(gx, got[1])
 
 
-@pytest.mark.parametrize("rows", [512, 25600])
-def test_fused_tail_counter_dropout_equals_unfused_node(rows):
+@pytest.mark.parametrize("rows,H,I", [(512, 64, 256), (25600, 64, 256), (512, 128, 512), (25600, 128, 512)])
+def test_fused_tail_counter_dropout_equals_unfused_node(rows, H, I):
     """In-kernel dropout: the fused launch and the unfused node draw the same keep decisions from the same seeds, so
     outputs and gradients agree to rounding; a different seed changes the output."""
-    H, I, eps, p = 64, 256, 1e-12, 0.5
+    eps, p = 1e-12, 0.5
     t, g = _inputs(rows, H, I, seed=7)
     cot = torch.randn(rows, H, generator=g).to(DEV)
     dev = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
@@ -89,10 +93,11 @@ def test_fused_tail_counter_dropout_equals_unfused_node(rows):
     assert torch.equal(again, outs[0])
 
 
-def test_fused_tail_row_selection_equals_gather_then_tail():
+@pytest.mark.parametrize("H,I", [(64, 256), (128, 512)])
+def test_fused_tail_row_selection_equals_gather_then_tail(H, I):
     """`pick`: the tail on selected positions of [B, L, H] inputs == gather, then the tail, then autograd's scatter
     (the tail is position-wise, abstract_recommender.py:130-134 reads one position per sequence)."""
-    B, L, R, H, I, eps, p = 37, 50, 3, 64, 256, 1e-12, 0.5
+    B, L, R, eps, p = 37, 50, 3, 1e-12, 0.5
     t, g = _inputs(B * L, H, I, seed=11)
     pick = torch.randint(0, L, (B, R), generator=g)
     cot = torch.randn(B, R, H, generator=g).to(DEV)
