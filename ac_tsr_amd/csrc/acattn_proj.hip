@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "acattn_common.h"
+#include "acattn_wstage.h"
 
 namespace {
 
@@ -403,8 +404,6 @@ __global__ void __launch_bounds__(64) proj_bwd_kernel(const acattn_proj_problem 
 // backward uses the same streamed product on TRANSPOSED copies of the weights (a 0.5 MB workspace filled by
 // transpose_weights_kernel in front of it: the dword gathers of the H = 64 backward would be 256 per product here).
 // ---------------------------------------------------------------------------------------------------------------------
-// weights travel in chunks of KT = 8 contraction tiles (128 input features: 8 float4 per lane); H = 256 has two per tile
-constexpr int KT = 8;
 // timing-only probe builds (tools/probe/build_proj_variant.sh; results are WRONG with any of them):
 //   ACATTN_PROJ_W0       every tile reads weight tile 0 (what the weight stream itself costs)
 //   ACATTN_PROJ_NOSTORE  no output stores                (what the output traffic costs)
@@ -436,22 +435,6 @@ __device__ __forceinline__ void chunk_product(const f4 (&w)[KT], int kc, const f
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma16(w[t][r], in[nb][KT * KC + t][r], acc[nb]);
   });
-}
-
-// a tile's four bias values per lane, requested BEFORE the tile's weights: the memory counter retires in order, so a
-// bias asked for after the next tile's weights would make the wait for it a wait for those weights too
-__device__ __forceinline__ f4 bias_tile(const float* bias, int n_out, int nt, int g) {
-  f4 b = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
-    const int j0 = 16 * nt + 4 * g;
-    if (j0 + 3 < n_out) {
-      b = *(const f4u*)(bias + j0);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) b[r] = bias[min(j0 + r, n_out - 1)];
-    }
-  }
-  return b;
 }
 
 // acc[nb][nt] (+)= W[16 nt ..][:] . in^T for nt = 0 .. DT - 1, kept in registers; the steps (tile, chunk) are unrolled
@@ -593,6 +576,146 @@ __global__ void __launch_bounds__(64, ACATTN_PROJ_WAVES) proj_wide_fwd_kernel(co
   product_emit<DT, NB>(P.wv, H, P.bv, H, c, g, xb, [&](int nt, const f4 (&a)[NB]) { store_tile(O.mv, H, H, nt, a); });
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same products with the weights staged through LDS, once per WORKGROUP [round 3, second form].  Measured on the
+// per-wave stream above (tools/gpu_pmc_proj.sh, probe builds): the matrix pipe is busy 39 % of the time, and neither the
+// weight addresses (always tile 0: same time), nor their coalescing, nor the L2 matter -- a CU's vector memory path
+// delivers ~10 B/clk (MI355X_MICROARCH.md, per-instruction constants) and eight waves each fetching 1 KB per 4 NB MFMAs
+// ask for 16.  Here the four waves of a workgroup fetch each weight chunk ONCE (2 float4 per lane instead of 8), park it
+// in LDS in fragment order (conflict-free ds_write_b128 / ds_read_b128, LDS delivers 128+ B/clk) and all read it from
+// there: a quarter of the vector-memory traffic, one workgroup barrier per 32 NB MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+// acc[nb][nt] (+)= W . in^T, kept in registers (see product_keep); `next` asks for the first chunk of whatever follows
+template <int DT, int NB, bool INIT, class Next>
+__device__ __forceinline__ void staged_keep(WeightStage& st, const float* w, const float* bias, const f4 (&in)[NB][DT],
+                                            f4 (&acc)[NB][DT], Next&& next) {
+  constexpr int H = 16 * DT, KC = DT / KT;
+  static_for<DT * KC>([&](auto k) {
+    constexpr int S = decltype(k)::value, NT = S / KC, C0 = S % KC;
+    f4 frag[KT], b;
+    st.fetch(frag, b);
+    if constexpr (S + 1 < DT * KC)
+      st.request(w, H, INIT ? bias : nullptr, H, (S + 1) / KC, (S + 1) % KC);
+    else
+      next();
+    PIN_ORDER();
+    f4 a[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) a[nb] = (INIT && C0 == 0) ? b : acc[nb][NT];
+    chunk_product<DT, NB>(frag, C0, in, a);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb][NT] = a[nb];
+    PIN_ORDER();
+    st.commit();
+  });
+}
+
+// the same for ceil(n_out / 16) tiles that are only emitted (see product_emit)
+template <int DT, int NB, class Emit, class Next>
+__device__ __forceinline__ void staged_emit(WeightStage& st, const float* w, int ld, const float* bias, int n_out,
+                                            const f4 (&in)[NB][DT], Emit&& emit, Next&& next) {
+  constexpr int KC = DT / KT;
+  const int n_tiles = (n_out + 15) >> 4;
+  for (int nt = 0; nt < n_tiles; ++nt) {
+    f4 a[NB];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      if (kc + 1 < KC)
+        st.request(w, ld, bias, n_out, nt, kc + 1);
+      else if (nt + 1 < n_tiles)
+        st.request(w, ld, bias, n_out, nt + 1, 0);
+      else
+        next();
+      PIN_ORDER();
+      if (kc == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) a[nb] = b;
+      }
+      chunk_product<DT, NB>(frag, kc, in, a);
+      PIN_ORDER();
+      st.commit();
+    }
+    emit(nt, a);
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ Rows<NB> wg_rows(int R, int wave) {
+  Rows<NB> w;
+  const int c = threadIdx.x & 15;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int r = ((blockIdx.x * NWV + wave) * NB + nb) * 16 + c;
+    w.ok[nb] = r < R;
+    w.row[nb] = r < R ? r : R - 1;
+  }
+  return w;
+}
+
+template <int H, int NB>
+__global__ void __launch_bounds__(64 * NWV, ACATTN_PROJ_WAVES) proj_staged_fwd_kernel(const acattn_proj_problem P, const acattn_proj_out O) {
+  constexpr int DT = H / 16;
+  __shared__ f4 stage_lds[2 * STAGE_F4];
+  WeightStage st;
+  st.lds = stage_lds;
+  st.par = 0;
+  st.lane = threadIdx.x & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  st.c = threadIdx.x & 15;
+  st.g = (threadIdx.x >> 4) & 3;
+  const int c = st.c, g = st.g;
+  const Rows<NB> W = wg_rows<NB>(P.rows, st.wave);  // (a wave past the last row keeps walking: the barriers need it)
+  st.request(P.wq, H, P.bq, H, 0, 0);
+  f4 xb[NB][DT], m[NB][DT];
+  load_rows<DT, NB>(P.x, W, g, xb);
+  st.par = 1;  // the first commit fills buffer 0 ...
+  st.commit();  // ... and flips back to it
+  auto store_tile = [&](float* out, int ld, int n_out, int nt, const f4 (&a)[NB]) {
+    const int j0 = 16 * nt + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (!W.ok[nb]) continue;
+      float* dst = out + (size_t)W.row[nb] * ld + j0;
+      if (j0 + 3 < n_out) {
+        *(f4u*)dst = a[nb];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j0 + r < n_out) dst[r] = a[nb][r];
+      }
+    }
+  };
+  auto masked_store_rows = [&](float* out, const f4 (&v)[NB][DT]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (W.ok[nb])
+#pragma unroll
+        for (int t = 0; t < DT; ++t) *(f4*)(out + (size_t)W.row[nb] * H + 16 * t + 4 * g) = v[nb][t];
+  };
+  staged_keep<DT, NB, true>(st, P.wq, P.bq, xb, m, [&] { st.request(P.waq, H, P.baq, H, 0, 0); });  // mq
+  masked_store_rows(O.mq, m);
+  if (O.affine) write_affine<DT, NB>(m, W, P, O.affine, 0, P.b_order[0], P.b_dist[0], 0, c, g);
+  staged_emit<DT, NB>(st, P.waq, H, P.baq, H, m, [&](int nt, const f4 (&a)[NB]) { store_tile(O.qa, H, H, nt, a); },
+                      [&] { if (P.wg) st.request(P.wg, H, P.bg, P.G, 0, 0); else st.request(P.wk, H, P.bk, H, 0, 0); });
+  if (P.wg) {
+    staged_emit<DT, NB>(st, P.wg, H, P.bg, P.G, m, [&](int nt, const f4 (&a)[NB]) {
+      f4 v[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) v[nb] = O.gate_prob ? gate_value(a[nb], 0) : a[nb];  // sigmoid once for all heads
+      store_tile(O.gate, P.G, P.G, nt, v);
+    }, [&] { st.request(P.wk, H, P.bk, H, 0, 0); });
+  }
+  staged_keep<DT, NB, true>(st, P.wk, P.bk, xb, m, [&] { st.request(P.wak, H, P.bak, H, 0, 0); });  // mk
+  masked_store_rows(O.mk, m);
+  if (O.affine) write_affine<DT, NB>(m, W, P, O.affine, H / P.n_heads, 0.f, 0.f, 2, c, g);
+  staged_emit<DT, NB>(st, P.wak, H, P.bak, H, m, [&](int nt, const f4 (&a)[NB]) { store_tile(O.ka, H, H, nt, a); },
+                      [&] { st.request(P.wv, H, P.bv, H, 0, 0); });
+  staged_emit<DT, NB>(st, P.wv, H, P.bv, H, xb, [&](int nt, const f4 (&a)[NB]) { store_tile(O.mv, H, H, nt, a); },
+                      [&] { st.has_bias = false; });
+}
+
 // transposed copies of the layer's weights for the backward: wt[m] = W_m^T as [n_in][ldt], ldt = n_out rounded up to 16
 // (pad columns zero), matrices in the order Wq, Wk, Wv, Waq, Wak ([H, H] each) and Wg ([G, H]) behind them
 struct TransposeJob {
@@ -698,6 +821,123 @@ __global__ void __launch_bounds__(64, 2) proj_wide_bwd_kernel(const acattn_proj_
   }
 }
 
+// the backward of proj_wide_bwd_kernel with the (transposed) weights staged through LDS once per workgroup
+template <int H, int NB, int MODE>
+__global__ void __launch_bounds__(64 * NWV, 2) proj_staged_bwd_kernel(const acattn_proj_problem P, const acattn_proj_bwd_io IO,
+                                                                      const float* __restrict__ wt) {
+  constexpr int DT = H / 16;
+  static_assert(DT == KT || MODE >= 0, "");
+  const bool h_dmq = MODE == 1 || (MODE == 0 && IO.dmq), h_dmk = MODE == 1 || (MODE == 0 && IO.dmk);
+  const bool h_dmv = MODE == 1 || (MODE == 0 && IO.dmv);
+  const bool h_dqa = MODE != 0 || IO.dqa, h_dka = MODE != 0 || IO.dka, h_dx = MODE != 0 || IO.dx;
+  const bool h_qt = MODE != 0 || IO.dmq_total, h_kt = MODE != 0 || IO.dmk_total;
+  const bool h_gate = MODE != 2 && IO.dgate && P.wg;
+  __shared__ f4 stage_lds[2 * STAGE_F4];
+  WeightStage st;
+  st.lds = stage_lds;
+  st.lane = threadIdx.x & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  st.c = threadIdx.x & 15;
+  st.g = (threadIdx.x >> 4) & 3;
+  const int c = st.c, g = st.g;
+  const Rows<NB> W = wg_rows<NB>(P.rows, st.wave);
+  const size_t HH = (size_t)H * H;
+  const float *wqT = wt, *wkT = wt + HH, *wvT = wt + 2 * HH, *waqT = wt + 3 * HH, *wakT = wt + 4 * HH, *wgT = wt + 5 * HH;
+  const int ldg = (P.G + 15) & ~15, GT = ldg >> 4;
+  // the chain of products (all flags are uniform over the launch): each asks for the first chunk of the next one
+  auto first = [&](const float* wT) { st.request(wT, H, nullptr, H, 0, 0); };
+  auto after_k_total = [&] { if (h_dx) first(wkT); else st.has_bias = false; };
+  auto after_q_total = [&] { if (h_dka) first(wakT); else after_k_total(); };
+  auto after_qa = [&] { if (h_gate) st.request_cols(wgT, ldg, 0); else after_q_total(); };
+  if (h_dqa) first(waqT); else after_qa();
+  st.par = 1;
+  f4 in[NB][DT], tot[NB][DT];
+  auto zero = [&](f4 (&v)[NB][DT]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int t = 0; t < DT; ++t) v[nb][t] = f4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto masked_store_rows = [&](float* out, const f4 (&v)[NB][DT]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      if (W.ok[nb])
+#pragma unroll
+        for (int t = 0; t < DT; ++t) *(f4*)(out + (size_t)W.row[nb] * H + 16 * t + 4 * g) = v[nb][t];
+  };
+  // ---- d mq (total) = dmq + dqa . Waq + dgate . Wg ------------------------------------------------------------------
+  if (h_dmq) load_rows<DT, NB>(IO.dmq, W, g, tot); else zero(tot);
+  if (h_dqa) load_rows<DT, NB>(IO.dqa, W, g, in);
+  st.commit();
+  if (h_dqa) staged_keep<DT, NB, false>(st, waqT, nullptr, in, tot, after_qa);
+  if (h_gate) {
+    // the contraction runs over the G gate outputs, 16 at a time: one staged chunk = the DT row tiles of WgT for that block
+    static_assert(DT == KT || DT == 2 * KT, "");
+    for (int kt = 0; kt < GT; ++kt) {
+      f4 d[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int j0 = 16 * kt + 4 * g;
+        const float* src = IO.dgate + (size_t)W.row[nb] * P.G + j0;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j0 + 3 < P.G) {
+          v = *(const f4u*)src;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j0 + r < P.G) v[r] = src[r];
+        }
+        d[nb] = v;
+      }
+#pragma unroll
+      for (int half = 0; half < DT / KT; ++half) {  // hidden 256: the 16 row tiles of a column block are two chunks
+        f4 frag[KT], b;
+        st.fetch(frag, b);
+        if (half + 1 < DT / KT)
+          st.request_cols(wgT + (size_t)(16 * KT) * ldg * (half + 1), ldg, kt);
+        else if (kt + 1 < GT)
+          st.request_cols(wgT, ldg, kt + 1);
+        else
+          after_q_total();
+        PIN_ORDER();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nt = 0; nt < KT; ++nt)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              // (compile-time index: the half loop is unrolled)
+              if (half == 0) tot[nb][nt] = mfma16(frag[nt][r], d[nb][r], tot[nb][nt]);
+              else tot[nb][DT - KT + nt] = mfma16(frag[nt][r], d[nb][r], tot[nb][DT - KT + nt]);
+            }
+        PIN_ORDER();
+        st.commit();
+      }
+    }
+  }
+  if (h_qt) masked_store_rows(IO.dmq_total, tot);
+  // ---- d mk (total) = dmk + dka . Wak ---------------------------------------------------------------------------------
+  if (h_dmk) load_rows<DT, NB>(IO.dmk, W, g, tot); else zero(tot);
+  if (h_dka) {
+    load_rows<DT, NB>(IO.dka, W, g, in);
+    staged_keep<DT, NB, false>(st, wakT, nullptr, in, tot, after_k_total);
+  }
+  if (h_kt) masked_store_rows(IO.dmk_total, tot);
+  // ---- dx = dx_init + d mk . Wk + d mq . Wq + d mv . Wv  (tot still holds d mk; d mq comes back from dmq_total) ----------
+  if (h_dx) {
+    f4 (&dx)[NB][DT] = in;
+    if (IO.dx_init) load_rows<DT, NB>(IO.dx_init, W, g, dx); else zero(dx);
+    staged_keep<DT, NB, false>(st, wkT, nullptr, tot, dx, [&] { first(wqT); });
+    load_rows<DT, NB>(IO.dmq_total, W, g, tot);
+    staged_keep<DT, NB, false>(st, wqT, nullptr, tot, dx, [&] { if (h_dmv) first(wvT); else st.has_bias = false; });
+    if (h_dmv) {
+      load_rows<DT, NB>(IO.dmv, W, g, tot);
+      staged_keep<DT, NB, false>(st, wvT, nullptr, tot, dx, [&] { st.has_bias = false; });
+    }
+    masked_store_rows(IO.dx, dx);
+  }
+}
+
 int rows_per_wave(int rows) {
   static const int forced = getenv("ACATTN_PROJ_ROWS_PER_WAVE") ? atoi(getenv("ACATTN_PROJ_ROWS_PER_WAVE")) : 0;  // measurements
   if (forced == 16 || forced == 32) return forced;
@@ -723,6 +963,12 @@ int launch_wide_fwd(const acattn_proj_problem& p, const acattn_proj_out& o, hipS
 #else
   constexpr int NB = H == 128 ? 2 : 1;
 #endif
+  static const bool per_wave = getenv("ACATTN_PROJ_PER_WAVE") != nullptr;  // measurement: the per-wave weight stream
+  if (!per_wave) {
+    const int blocks = (p.rows + 16 * NB * NWV - 1) / (16 * NB * NWV);
+    hipLaunchKernelGGL((proj_staged_fwd_kernel<H, NB>), dim3(blocks), dim3(64 * NWV), 0, stream, p, o);
+    return (int)hipGetLastError();
+  }
   const int blocks = (p.rows + 16 * NB - 1) / (16 * NB);
   hipLaunchKernelGGL((proj_wide_fwd_kernel<H, NB>), dim3(blocks), dim3(64), 0, stream, p, o);
   return (int)hipGetLastError();
@@ -747,11 +993,22 @@ int launch_wide_bwd(const acattn_proj_problem& p, const acattn_proj_bwd_io& io, 
   }
   const int max_out = std::max(p.H, (p.G + 15) & ~15);
   hipLaunchKernelGGL(transpose_weights_kernel, dim3(max_out / 16, p.H / 16, p.wg ? 6 : 5), dim3(256), 0, stream, J, p.H, wt);
-  const int blocks = (p.rows + 16 * NB - 1) / (16 * NB);
   const bool outs = io.dx && io.dmq_total && io.dmk_total, attack = io.dqa && io.dka;
   const bool all_in = attack && io.dmq && io.dmk && io.dmv && (io.dgate || !p.wg);
   const bool attack_only = attack && !io.dmq && !io.dmk && !io.dmv && !io.dgate;
   const int mode = !outs ? 0 : all_in ? 1 : attack_only ? 2 : 0;
+  static const bool per_wave = getenv("ACATTN_PROJ_PER_WAVE") != nullptr;  // measurement: the per-wave weight stream
+  if (!per_wave) {
+    const int wgs = (p.rows + 16 * NB * NWV - 1) / (16 * NB * NWV);
+    if (mode == 1)
+      hipLaunchKernelGGL((proj_staged_bwd_kernel<H, NB, 1>), dim3(wgs), dim3(64 * NWV), 0, stream, p, io, (const float*)wt);
+    else if (mode == 2)
+      hipLaunchKernelGGL((proj_staged_bwd_kernel<H, NB, 2>), dim3(wgs), dim3(64 * NWV), 0, stream, p, io, (const float*)wt);
+    else
+      hipLaunchKernelGGL((proj_staged_bwd_kernel<H, NB, 0>), dim3(wgs), dim3(64 * NWV), 0, stream, p, io, (const float*)wt);
+    return (int)hipGetLastError();
+  }
+  const int blocks = (p.rows + 16 * NB - 1) / (16 * NB);
   if (mode == 1)
     hipLaunchKernelGGL((proj_wide_bwd_kernel<H, NB, 1>), dim3(blocks), dim3(64), 0, stream, p, io, (const float*)wt);
   else if (mode == 2)

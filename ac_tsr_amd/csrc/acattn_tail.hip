@@ -40,6 +40,7 @@
 
 #include "acattn_common.h"
 #include "acattn_rowops.h"
+#include "acattn_wstage.h"
 
 int acattn_tail_bwd_partial_rows(int rows);
 int acattn_tail_bwd_partial_rows_h(int rows, int H);
@@ -883,13 +884,306 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) tail_wide_bwd_kernel
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Many rows (> 8192): the same chains with every weight chunk staged through LDS once per workgroup of four waves
+// (acattn_wstage.h; measurement above proj_staged_fwd_kernel in acattn_proj.hip: a CU's vector memory path, not the
+// matrix pipe, bounded the per-wave stream).  A chunk is what one MFMA group of 32 reads: a 16-row tile of Wd, a slab of
+// dense_1 (with its bias), the same slab's columns of dense_2; they are consumed in exactly the order they are asked for.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ Rows<NB> wg_tail_rows(const acattn_tail_problem& P, int wave) {
+  Rows<NB> w;
+  const int c = threadIdx.x & 15, R = P.rows;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int r = ((blockIdx.x * NWV + wave) * NB + nb) * 16 + c;
+    w.ok[nb] = r < R;
+    w.row[nb] = r < R ? r : R - 1;
+    w.src[nb] = P.src_index
+                    ? (int64_t)(w.row[nb] / P.src_R) * P.src_L + min(max((int)P.src_index[w.row[nb]], 0), P.src_L - 1)
+                    : w.row[nb];
+  }
+  return w;
+}
+
+__device__ __forceinline__ void stage_init(WeightStage& st, f4* lds) {
+  st.lds = lds;
+  st.par = 1;  // the first commit fills buffer 0 and flips back to it
+  st.lane = threadIdx.x & 63;
+  st.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  st.c = threadIdx.x & 15;
+  st.g = (threadIdx.x >> 4) & 3;
+  st.has_bias = false;
+}
+
+template <int H, int I>
+__global__ void __launch_bounds__(64 * NWV, 2) tail_staged_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
+  constexpr int DT = H / 16, IT = I / 16;
+  static_assert(DT == KT, "hidden 128");
+  __shared__ f4 stage_lds[2 * STAGE_F4];
+  WeightStage st;
+  stage_init(st, stage_lds);
+  const int c = st.c, g = st.g;
+  const Rows<1> W = wg_tail_rows<1>(P, st.wave);  // (a wave past the last row keeps walking: the barriers need it)
+  const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
+  const int row = W.row[0];
+  const bool ok = W.ok[0];
+  st.request(P.wd, H, P.bd, H, 0, 0);
+
+  // ---- h1 = dense(ctx) + bias;  a = LayerNorm(dropout(h1) + x) ---------------------------------------------------------
+  f4 a[DT];
+  {
+    f4 cb[DT], res[DT], h1[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      cb[t] = *(const f4*)(P.ctx + (size_t)W.src[0] * H + 16 * t + 4 * g);
+      res[t] = *(const f4*)(P.x + (size_t)W.src[0] * H + 16 * t + 4 * g);
+    }
+    st.commit();
+    static_for<DT>([&](auto k) {
+      constexpr int NT = decltype(k)::value;
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      if constexpr (NT + 1 < DT) st.request(P.wd, H, P.bd, H, NT + 1, 0); else st.request(P.w1, H, P.bb1, I, 0, 0);
+      PIN_ORDER();
+      f4 acc[2] = {b, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r & 1] = mfma16(frag[t][r], cb[t][r], acc[r & 1]);
+      h1[NT] = acc[0] + acc[1];
+      PIN_ORDER();
+      st.commit();
+    });
+    f4 keep[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, row, 4 * t + g, H);
+    float mean, rstd;
+    ln_forward_mem<DT>(h1, res, keep, P.g1, P.b1, g, P.eps1, a, mean, rstd);
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)row * H + 16 * t + 4 * g;
+        *(f4*)(S.h1 + o) = h1[t];
+        *(f4*)(S.a + o) = a[t];
+      }
+      if (g == 0) *(float2*)(S.st1 + 2 * (size_t)row) = float2{mean, rstd};
+    }
+  }
+
+  // ---- h3 = dense_2(gelu(dense_1(a))), one inner slab (16 columns) at a time: two chunks per slab -------------------------
+  f4 h3[DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt) h3[nt] = *(const f4*)(P.bb2 + 16 * nt + 4 * g);
+  for (int mt = 0; mt < IT; ++mt) {
+    f4 act;
+    {
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      st.request_cols(P.w2, I, mt);  // A[n = 16t+c][m = 16mt+4g+r]
+      PIN_ORDER();
+      f4 h2[2] = {b, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[r & 1] = mfma16(frag[t][r], a[t][r], h2[r & 1]);
+      const f4 pre = h2[0] + h2[1];
+      f4 dact;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const PhiExp pe = phi_exp(pre[r]);
+        act[r] = pre[r] * pe.phi;
+        dact[r] = fmaf(pre[r] * kInvSqrt2Pi, pe.e, pe.phi);
+      }
+      if (ok) {
+        *(f4*)(S.act + (size_t)row * I + 16 * mt + 4 * g) = act;
+        if (S.gelu_grad) *(f4*)(S.gelu_grad + (size_t)row * I + 16 * mt + 4 * g) = dact;
+      }
+      PIN_ORDER();
+      st.commit();
+    }
+    {
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      if (mt + 1 < IT) st.request(P.w1, H, P.bb1, I, mt + 1, 0); else st.has_bias = false;
+      PIN_ORDER();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt) h3[nt] = mfma16(frag[nt][r], act[r], h3[nt]);
+      PIN_ORDER();
+      st.commit();
+    }
+  }
+
+  // ---- out = LayerNorm(dropout(h3) + a) -------------------------------------------------------------------------
+  {
+    f4 keep[DT], y[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) keep[t] = row_keep_scale(P.p2, P.keep2, P.seed2 + step, row, 4 * t + g, H);
+    float mean, rstd;
+    ln_forward_mem<DT>(h3, a, keep, P.g2, P.b2, g, P.eps2, y, mean, rstd);
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const size_t o = (size_t)row * H + 16 * t + 4 * g;
+        *(f4*)(S.h3 + o) = h3[t];
+        *(f4*)(S.out + o) = y[t];
+      }
+      if (g == 0) *(float2*)(S.st2 + 2 * (size_t)row) = float2{mean, rstd};
+    }
+  }
+}
+
+template <int H, int I, bool SAVED>
+__global__ void __launch_bounds__(64 * NWV, 2) tail_staged_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
+                                                                      const acattn_tail_bwd_io IO, const float* __restrict__ ws) {
+  constexpr int DT = H / 16, IT = I / 16;
+  static_assert(DT == KT, "hidden 128");
+  __shared__ f4 stage_lds[2 * STAGE_F4];
+  WeightStage st;
+  stage_init(st, stage_lds);
+  const int c = st.c, g = st.g;
+  const Rows<1> W = wg_tail_rows<1>(P, st.wave);
+  const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
+  const int row = W.row[0];
+  const bool ok = W.ok[0];
+  // one partial row per ROW BLOCK, as in the per-wave kernels
+  float* part = IO.dgb_part ? IO.dgb_part + (size_t)(blockIdx.x * NWV + st.wave) * 4 * H : nullptr;
+  const bool write_part = (blockIdx.x * NWV + st.wave) * 16 < P.rows;
+  const float *w1T = ws, *w2T = ws + (size_t)H * I, *wdT = ws + 2 * (size_t)H * I;
+  if (SAVED) st.request(w2T, H, nullptr, I, 0, 0); else st.request(P.w1, H, P.bb1, I, 0, 0);
+
+  // ---- through the second LayerNorm: d h3 (after the dropout), d a (residual share) -------------------------------
+  f4 a[SAVED ? 1 : DT], dh3[DT], da[DT];
+  {
+    f4 z[DT], keep[DT], dy[DT], av[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const size_t o = (size_t)row * H + 16 * t + 4 * g;
+      z[t] = *(const f4*)(S.h3 + o);
+      av[t] = *(const f4*)(S.a + o);
+      dy[t] = *(const f4*)(IO.d_out + o);
+      keep[t] = row_keep_scale(P.p2, P.keep2, P.seed2 + step, row, 4 * t + g, H);
+    }
+    st.commit();
+    const float2 st2 = *(const float2*)(S.st2 + 2 * (size_t)row);
+    ln_backward_wide<DT>(z, av, keep, P.g2, st2.x, st2.y, dy, ok, write_part, c, g, da, part ? part + 2 * H : nullptr,
+                         part ? part + 3 * H : nullptr);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      dh3[t] = da[t] * keep[t];
+      if (IO.d_h3 && ok) *(f4*)(IO.d_h3 + (size_t)row * H + 16 * t + 4 * g) = dh3[t];
+      if constexpr (!SAVED) a[t] = av[t];
+    }
+  }
+
+  // ---- d a += W1^T (gelu'(h2) * (W2^T d h3)), slab by slab --------------------------------------------------------------
+  for (int mt = 0; mt < IT; ++mt) {
+    f4 gp;  // gelu'(h2) of the slab
+    if constexpr (SAVED) {
+      gp = *(const f4*)(S.gelu_grad + (size_t)row * I + 16 * mt + 4 * g);
+    } else {
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      st.request(w2T, H, nullptr, I, mt, 0);
+      PIN_ORDER();
+      f4 h2[2] = {b, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[r & 1] = mfma16(frag[t][r], a[t][r], h2[r & 1]);
+      const f4 pre = h2[0] + h2[1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gp[r] = gelu_erf_grad(pre[r]);
+      PIN_ORDER();
+      st.commit();
+    }
+    f4 dh2;
+    {
+      f4 frag[KT], b;  // dense_2^T: A[m = 16mt+c][n = 16t+4g+r] = W2[n][m]
+      st.fetch(frag, b);
+      st.request_cols(w1T, I, mt);
+      PIN_ORDER();
+      f4 dact[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dact[r & 1] = mfma16(frag[t][r], dh3[t][r], dact[r & 1]);
+      dh2 = (dact[0] + dact[1]) * gp;
+      if (IO.d_h2 && ok) *(f4*)(IO.d_h2 + (size_t)row * I + 16 * mt + 4 * g) = dh2;
+      PIN_ORDER();
+      st.commit();
+    }
+    {
+      f4 frag[KT], b;  // dense_1^T: A[k = 16nt+c][m = 16mt+4g+r] = W1[m][k]
+      st.fetch(frag, b);
+      if (mt + 1 < IT) {
+        if (SAVED) st.request(w2T, H, nullptr, I, mt + 1, 0); else st.request(P.w1, H, P.bb1, I, mt + 1, 0);
+      } else {
+        st.request(wdT, H, nullptr, H, 0, 0);
+      }
+      PIN_ORDER();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < DT; ++nt) da[nt] = mfma16(frag[nt][r], dh2[r], da[nt]);
+      PIN_ORDER();
+      st.commit();
+    }
+  }
+
+  // ---- through the first LayerNorm: d h1, d x; then d ctx = d h1 . Wd ---------------------------------------------
+  f4 dh1[DT];
+  {
+    f4 z[DT], res[DT], keep[DT], dz[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const size_t o = (size_t)row * H + 16 * t + 4 * g;
+      z[t] = *(const f4*)(S.h1 + o);
+      res[t] = *(const f4*)(P.x + (size_t)W.src[0] * H + 16 * t + 4 * g);
+      keep[t] = row_keep_scale(P.p1, P.keep1, P.seed1 + step, row, 4 * t + g, H);
+    }
+    const float2 st1 = *(const float2*)(S.st1 + 2 * (size_t)row);
+    ln_backward_wide<DT>(z, res, keep, P.g1, st1.x, st1.y, da, ok, write_part, c, g, dz, part, part ? part + H : nullptr);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const size_t o = (size_t)row * H + 16 * t + 4 * g;
+      dh1[t] = dz[t] * keep[t];
+      if (ok) {
+        if (IO.d_x) store_grad(IO.d_x + (size_t)W.src[0] * H + 16 * t + 4 * g, dz[t], P.src_index != nullptr);
+        if (IO.d_h1) *(f4*)(IO.d_h1 + o) = dh1[t];
+      }
+    }
+  }
+  // dense^T: A[k = 16nt+c][n = 16t+4g+r] = Wd[n][k] = WdT[16nt+c][16t+4g+r]  (walked also without d_ctx: the barriers)
+  static_for<DT>([&](auto k) {
+    constexpr int NT = decltype(k)::value;
+    f4 frag[KT], b;
+    st.fetch(frag, b);
+    if constexpr (NT + 1 < DT) st.request(wdT, H, nullptr, H, NT + 1, 0);
+    PIN_ORDER();
+    f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r & 1] = mfma16(frag[t][r], dh1[t][r], acc[r & 1]);
+    if (IO.d_ctx && ok) store_grad(IO.d_ctx + (size_t)W.src[0] * H + 16 * NT + 4 * g, acc[0] + acc[1], P.src_index != nullptr);
+    PIN_ORDER();
+    if constexpr (NT + 1 < DT) st.commit();
+  });
+}
+
 template <int H, int I>
 int launch_wide_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
   const int blocks = (p.rows + 15) / 16;
+  static const bool per_wave = getenv("ACATTN_TAIL_PER_WAVE") != nullptr;  // measurement: the per-wave weight stream
   if (wide_split(p.rows))
     hipLaunchKernelGGL((tail_wide_fwd_kernel<H, I, 4>), dim3(blocks), dim3(256), 0, stream, p, s);
-  else
+  else if (per_wave)
     hipLaunchKernelGGL((tail_wide_fwd_kernel<H, I, 1>), dim3(blocks), dim3(64), 0, stream, p, s);
+  else
+    hipLaunchKernelGGL((tail_staged_fwd_kernel<H, I>), dim3((blocks + NWV - 1) / NWV), dim3(64 * NWV), 0, stream, p, s);
   return (int)hipGetLastError();
 }
 
@@ -903,6 +1197,15 @@ int launch_wide_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, co
   hipLaunchKernelGGL(tail_transpose_kernel, dim3(I / 16, I / 16, 3), dim3(256), 0, stream, p.w1, p.w2, p.wd, H, I, ws);
   const int blocks = (p.rows + 15) / 16;
   const bool split = wide_split(p.rows);
+  static const bool per_wave = getenv("ACATTN_TAIL_PER_WAVE") != nullptr;  // measurement: the per-wave weight stream
+  if (!split && !per_wave) {
+    const int wgs = (blocks + NWV - 1) / NWV;
+    if (s.gelu_grad)
+      hipLaunchKernelGGL((tail_staged_bwd_kernel<H, I, true>), dim3(wgs), dim3(64 * NWV), 0, stream, p, s, io, (const float*)ws);
+    else
+      hipLaunchKernelGGL((tail_staged_bwd_kernel<H, I, false>), dim3(wgs), dim3(64 * NWV), 0, stream, p, s, io, (const float*)ws);
+    return (int)hipGetLastError();
+  }
   if (s.gelu_grad) {
     if (split)
       hipLaunchKernelGGL((tail_wide_bwd_kernel<H, I, 4, true>), dim3(blocks), dim3(256), 0, stream, p, s, io, (const float*)ws);
