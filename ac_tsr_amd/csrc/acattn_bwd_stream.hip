@@ -44,6 +44,10 @@ __device__ __forceinline__ float row16_sum(float v) {  // over the 16 lanes of a
   return v;
 }
 
+// head sizes from this one up run one wave per SIMD (probe: -DACATTN_BWD_ONE_WAVE_DH=32)
+#ifndef ACATTN_BWD_ONE_WAVE_DH
+#define ACATTN_BWD_ONE_WAVE_DH 64
+#endif
 constexpr int NSC = 8;  // floats per row in the workspace: da, dc, r1, sP, sM, (3 spare)
 
 // Everything a lane knows about ITS query row (row i0 + c of one query block) that does not depend on the key tile.
@@ -359,7 +363,7 @@ __device__ __forceinline__ void key_affine(const f4 (&k4)[DH / 16], const float 
 // row kernel
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ void __launch_bounds__(64, DH >= 64 ? 1 : 2) acattn_bwd_row_kernel(const acattn_problem P, const acattn_bwd_io IO, float* __restrict__ ws) {
+__global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acattn_bwd_row_kernel(const acattn_problem P, const acattn_bwd_io IO, float* __restrict__ ws) {
   constexpr int KS = DH / 4, DT = DH / 16;
   const int L = P.L, H = P.H, nh = P.n_heads;
   const int nT = (L + 15) >> 4;
@@ -537,7 +541,7 @@ __global__ void __launch_bounds__(64, DH >= 64 ? 1 : 2) acattn_bwd_row_kernel(co
 // key kernel
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH>
-__global__ void __launch_bounds__(64, DH >= 64 ? 1 : 2) acattn_bwd_key_kernel(const acattn_problem P, const acattn_bwd_io IO, const float* __restrict__ ws) {
+__global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acattn_bwd_key_kernel(const acattn_problem P, const acattn_bwd_io IO, const float* __restrict__ ws) {
   constexpr int KS = DH / 4, DT = DH / 16;
   constexpr int TS = 20;  // row stride of a transposed 16 x 16 tile in LDS (16-byte aligned rows, conflict-free reads)
   __shared__ __attribute__((aligned(16))) float tr[4][16 * TS + 32];
