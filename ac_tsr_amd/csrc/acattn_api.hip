@@ -240,7 +240,7 @@ int acattn_projections_bwd(const acattn_proj_problem* p, const acattn_proj_bwd_i
 static int check_tail(const acattn_tail_problem* p, const acattn_tail_saved* s) {
   if (!p || !s) return fail("problem and saved must be non-NULL");
   if (p->rows < 1) return fail("rows must be positive");
-  if (!acattn_tail_supported(p->H, p->I)) return fail("layer tail: (hidden_size, inner_size) must be (64, 256), (64, 128), (128, 512) or (128, 256)");
+  if (!acattn_tail_supported(p->H, p->I)) return fail("layer tail: (hidden_size, inner_size) must be (64, 256), (64, 128), (128, 512), (128, 256) or (256, 1024)");
   if (!p->ctx || !p->x || !p->wd || !p->bd || !p->g1 || !p->b1 || !p->w1 || !p->bb1 || !p->w2 || !p->bb2 || !p->g2 || !p->b2)
     return fail("layer tail: inputs and parameters must be non-NULL");
   if (!(p->p1 >= 0.f && p->p1 < 1.f) || !(p->p2 >= 0.f && p->p2 < 1.f)) return fail("dropout probabilities must be in [0, 1)");

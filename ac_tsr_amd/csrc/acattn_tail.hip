@@ -159,6 +159,8 @@ __device__ __forceinline__ void ln_forward_mem(const f4 (&z)[DT], const f4 (&res
   for (int t = 0; t < DT; ++t) y[t] = (y[t] * rstd) * *(const f4*)(gamma + 16 * t + 4 * g) + *(const f4*)(beta + 16 * t + 4 * g);
 }
 
+__device__ __forceinline__ float hsum4(const f4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
 template <int DT>
 __device__ __forceinline__ void load_cols(const float* v, int g, f4 (&out)[DT]) {
 #pragma unroll
@@ -1174,16 +1176,347 @@ __global__ void __launch_bounds__(64 * NWV, 2) tail_staged_bwd_kernel(const acat
   });
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Hidden 256 (BASELINE configs[4]; also runs at 128: ACATTN_TAIL_CHUNKED=1, the tests' cross-check): the staged chains
+// with a tile's contraction split into H / 128 chunks and the LayerNorms STREAMED -- at 16 feature tiles per row four
+// row-sized register arrays (value, residual, keep, cotangent) do not fit next to the chain's own two, so the forward
+// normalises in place as the tiles of a product arrive and the backward walks its LayerNorm inputs twice (statistics,
+// then gradients; the second walk hits L1 / L2).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int H, int I>
+__global__ void __launch_bounds__(64 * NWV, H > 128 ? 1 : 2) tail_chunked_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
+  constexpr int DT = H / 16, IT = I / 16, KC = DT / KT;
+  constexpr float inv_h = 1.0f / H;
+  __shared__ f4 stage_lds[2 * STAGE_F4];
+  WeightStage st;
+  stage_init(st, stage_lds);
+  const int c = st.c, g = st.g;
+  const Rows<1> W = wg_tail_rows<1>(P, st.wave);
+  const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
+  const int row = W.row[0];
+  const bool ok = W.ok[0];
+  st.request(P.wd, H, P.bd, H, 0, 0);
+
+  // ---- h1 = dense(ctx) + bias, tile by tile;  z = dropout(h1) + x collected in `a`;  a = LayerNorm(z) in place -----------
+  f4 a[DT];
+  {
+    f4 cb[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) cb[t] = *(const f4*)(P.ctx + (size_t)W.src[0] * H + 16 * t + 4 * g);
+    st.commit();
+    float sum = 0.f;
+    static_for<DT>([&](auto k) {
+      constexpr int NT = decltype(k)::value;
+      const f4 res = *(const f4*)(P.x + (size_t)W.src[0] * H + 16 * NT + 4 * g);  // (in flight under the tile's MFMAs)
+      f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, bias;
+      static_for<KC>([&](auto q) {
+        constexpr int C0 = decltype(q)::value;
+        f4 frag[KT], b;
+        st.fetch(frag, b);
+        if constexpr (C0 == 0) bias = b;
+        if constexpr (C0 + 1 < KC) st.request(P.wd, H, P.bd, H, NT, C0 + 1);
+        else if constexpr (NT + 1 < DT) st.request(P.wd, H, P.bd, H, NT + 1, 0);
+        else st.request(P.w1, H, P.bb1, I, 0, 0);
+        PIN_ORDER();
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r & 1] = mfma16(frag[t][r], cb[KT * C0 + t][r], acc[r & 1]);
+        PIN_ORDER();
+        st.commit();
+      });
+      const f4 h1 = (acc[0] + acc[1]) + bias;
+      if (ok) *(f4*)(S.h1 + (size_t)row * H + 16 * NT + 4 * g) = h1;
+      const f4 z = h1 * row_keep_scale(P.p1, P.keep1, P.seed1 + step, row, 4 * NT + g, H) + res;
+      a[NT] = z;
+      sum += hsum4(z);
+    });
+    const float mean = quad_sum(sum) * inv_h;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      a[t] = a[t] - mean;
+      sq += hsum4(a[t] * a[t]);
+    }
+    const float rstd = __builtin_amdgcn_rsqf(quad_sum(sq) * inv_h + P.eps1);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      a[t] = (a[t] * rstd) * *(const f4*)(P.g1 + 16 * t + 4 * g) + *(const f4*)(P.b1 + 16 * t + 4 * g);
+      if (ok) *(f4*)(S.a + (size_t)row * H + 16 * t + 4 * g) = a[t];
+    }
+    if (ok && g == 0) *(float2*)(S.st1 + 2 * (size_t)row) = float2{mean, rstd};
+  }
+
+  // ---- h3 = dense_2(gelu(dense_1(a))), one inner slab at a time: KC chunks of dense_1's slab, KC of dense_2's columns ------
+  f4 h3[DT];
+#pragma unroll
+  for (int nt = 0; nt < DT; ++nt) h3[nt] = *(const f4*)(P.bb2 + 16 * nt + 4 * g);
+  for (int mt = 0; mt < IT; ++mt) {
+    f4 h2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, bias;
+    static_for<KC>([&](auto q) {
+      constexpr int C0 = decltype(q)::value;
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      if constexpr (C0 == 0) bias = b;
+      if constexpr (C0 + 1 < KC) st.request(P.w1, H, P.bb1, I, mt, C0 + 1); else st.request_cols(P.w2, I, mt);
+      PIN_ORDER();
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[r & 1] = mfma16(frag[t][r], a[KT * C0 + t][r], h2[r & 1]);
+      PIN_ORDER();
+      st.commit();
+    });
+    const f4 pre = (h2[0] + h2[1]) + bias;
+    f4 act, dact;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const PhiExp pe = phi_exp(pre[r]);
+      act[r] = pre[r] * pe.phi;
+      dact[r] = fmaf(pre[r] * kInvSqrt2Pi, pe.e, pe.phi);
+    }
+    if (ok) {
+      *(f4*)(S.act + (size_t)row * I + 16 * mt + 4 * g) = act;
+      if (S.gelu_grad) *(f4*)(S.gelu_grad + (size_t)row * I + 16 * mt + 4 * g) = dact;
+    }
+    static_for<KC>([&](auto q) {
+      constexpr int C0 = decltype(q)::value;
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      if constexpr (C0 + 1 < KC) {
+        st.request_cols(P.w2 + (size_t)(16 * KT * (C0 + 1)) * I, I, mt);
+      } else {
+        if (mt + 1 < IT) st.request(P.w1, H, P.bb1, I, mt + 1, 0); else st.has_bias = false;
+      }
+      PIN_ORDER();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < KT; ++nt) h3[KT * C0 + nt] = mfma16(frag[nt][r], act[r], h3[KT * C0 + nt]);
+      PIN_ORDER();
+      st.commit();
+    });
+  }
+
+  // ---- out = LayerNorm(dropout(h3) + a), in place in h3 ----------------------------------------------------------------
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      if (ok) *(f4*)(S.h3 + (size_t)row * H + 16 * t + 4 * g) = h3[t];
+      h3[t] = h3[t] * row_keep_scale(P.p2, P.keep2, P.seed2 + step, row, 4 * t + g, H) + a[t];
+      sum += hsum4(h3[t]);
+    }
+    const float mean = quad_sum(sum) * inv_h;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      h3[t] = h3[t] - mean;
+      sq += hsum4(h3[t] * h3[t]);
+    }
+    const float rstd = __builtin_amdgcn_rsqf(quad_sum(sq) * inv_h + P.eps2);
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+        *(f4*)(S.out + (size_t)row * H + 16 * t + 4 * g) =
+            (h3[t] * rstd) * *(const f4*)(P.g2 + 16 * t + 4 * g) + *(const f4*)(P.b2 + 16 * t + 4 * g);
+      if (g == 0) *(float2*)(S.st2 + 2 * (size_t)row) = float2{mean, rstd};
+    }
+  }
+}
+
+// LayerNorm backward in two walks over its inputs in memory (z = pre-dropout value at `zp`, residual at `rp`; the cotangent
+// comes from `dyp` or, when that is NULL, from the registers `dyr`): dz lands in `dz`
+template <int DT, class Keep>
+__device__ __forceinline__ void ln_backward_streamed(const float* zp, const float* rp, const float* dyp, const f4 (&dyr)[DT],
+                                                     Keep&& keep_of, const float* gamma, float mean, float rstd, bool ok,
+                                                     bool write_part, int c, int g, f4 (&dz)[DT], float* part_g, float* part_b) {
+  constexpr float inv_h = 1.0f / (16 * DT);
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    const f4 xh = ((*(const f4*)(zp + 16 * t + 4 * g) * keep_of(t) + *(const f4*)(rp + 16 * t + 4 * g)) - mean) * rstd;
+    const f4 dy = dyp ? *(const f4*)(dyp + 16 * t + 4 * g) : dyr[t];
+    const f4 gg = dy * *(const f4*)(gamma + 16 * t + 4 * g);
+    m1 += hsum4(gg);
+    m2 += hsum4(gg * xh);
+    if (part_g) {
+      f4 pg, pb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pg[r] = dpp_row_sum(ok ? dy[r] * xh[r] : 0.f);
+        pb[r] = dpp_row_sum(ok ? dy[r] : 0.f);
+      }
+      if (c == 0 && write_part) {
+        *(f4*)(part_g + 16 * t + 4 * g) = pg;
+        *(f4*)(part_b + 16 * t + 4 * g) = pb;
+      }
+    }
+  }
+  m1 = quad_sum(m1) * inv_h;
+  m2 = quad_sum(m2) * inv_h;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    const f4 xh = ((*(const f4*)(zp + 16 * t + 4 * g) * keep_of(t) + *(const f4*)(rp + 16 * t + 4 * g)) - mean) * rstd;
+    const f4 dy = dyp ? *(const f4*)(dyp + 16 * t + 4 * g) : dyr[t];
+    const f4 gg = dy * *(const f4*)(gamma + 16 * t + 4 * g);
+    dz[t] = (gg - m1 - xh * m2) * rstd;
+  }
+}
+
+template <int H, int I, bool SAVED>
+__global__ void __launch_bounds__(64 * NWV, H > 128 ? 1 : 2) tail_chunked_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
+                                                                       const acattn_tail_bwd_io IO, const float* __restrict__ ws) {
+  constexpr int DT = H / 16, IT = I / 16, KC = DT / KT;
+  __shared__ f4 stage_lds[2 * STAGE_F4];
+  WeightStage st;
+  stage_init(st, stage_lds);
+  const int c = st.c, g = st.g;
+  const Rows<1> W = wg_tail_rows<1>(P, st.wave);
+  const uint64_t step = P.seed_device ? *P.seed_device : 0ull;
+  const int row = W.row[0];
+  const bool ok = W.ok[0];
+  float* part = IO.dgb_part ? IO.dgb_part + (size_t)(blockIdx.x * NWV + st.wave) * 4 * H : nullptr;
+  const bool write_part = (blockIdx.x * NWV + st.wave) * 16 < P.rows;
+  const float *w1T = ws, *w2T = ws + (size_t)H * I, *wdT = ws + 2 * (size_t)H * I;
+  if (SAVED) st.request(w2T, H, nullptr, I, 0, 0); else st.request(P.w1, H, P.bb1, I, 0, 0);
+
+  // ---- through the second LayerNorm: d h3 (after the dropout), d a (residual share) -------------------------------
+  f4 a[SAVED ? 1 : DT], dh3[DT], da[DT];
+  {
+    auto keep2 = [&](int t) { return row_keep_scale(P.p2, P.keep2, P.seed2 + step, row, 4 * t + g, H); };
+    const float2 st2 = *(const float2*)(S.st2 + 2 * (size_t)row);
+    st.commit();
+    ln_backward_streamed<DT>(S.h3 + (size_t)row * H, S.a + (size_t)row * H, IO.d_out + (size_t)row * H, da, keep2, P.g2, st2.x,
+                             st2.y, ok, write_part, c, g, da, part ? part + 2 * H : nullptr, part ? part + 3 * H : nullptr);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      dh3[t] = da[t] * keep2(t);
+      if (IO.d_h3 && ok) *(f4*)(IO.d_h3 + (size_t)row * H + 16 * t + 4 * g) = dh3[t];
+      if constexpr (!SAVED) a[t] = *(const f4*)(S.a + (size_t)row * H + 16 * t + 4 * g);
+    }
+  }
+
+  // ---- d a += W1^T (gelu'(h2) * (W2^T d h3)), slab by slab --------------------------------------------------------------
+  for (int mt = 0; mt < IT; ++mt) {
+    f4 gp;  // gelu'(h2) of the slab
+    if constexpr (SAVED) {
+      gp = *(const f4*)(S.gelu_grad + (size_t)row * I + 16 * mt + 4 * g);
+    } else {
+      f4 h2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, bias;
+      static_for<KC>([&](auto q) {
+        constexpr int C0 = decltype(q)::value;
+        f4 frag[KT], b;
+        st.fetch(frag, b);
+        if constexpr (C0 == 0) bias = b;
+        if constexpr (C0 + 1 < KC) st.request(P.w1, H, P.bb1, I, mt, C0 + 1); else st.request(w2T, H, nullptr, I, mt, 0);
+        PIN_ORDER();
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h2[r & 1] = mfma16(frag[t][r], a[SAVED ? 0 : KT * C0 + t][r], h2[r & 1]);
+        PIN_ORDER();
+        st.commit();
+      });
+      const f4 pre = (h2[0] + h2[1]) + bias;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gp[r] = gelu_erf_grad(pre[r]);
+    }
+    f4 dact[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+    static_for<KC>([&](auto q) {  // dense_2^T: A[m = 16mt+c][n = 16t+4g+r] = W2[n][m]
+      constexpr int C0 = decltype(q)::value;
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      if constexpr (C0 + 1 < KC) st.request(w2T, H, nullptr, I, mt, C0 + 1); else st.request_cols(w1T, I, mt);
+      PIN_ORDER();
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dact[r & 1] = mfma16(frag[t][r], dh3[KT * C0 + t][r], dact[r & 1]);
+      PIN_ORDER();
+      st.commit();
+    });
+    const f4 dh2 = (dact[0] + dact[1]) * gp;
+    if (IO.d_h2 && ok) *(f4*)(IO.d_h2 + (size_t)row * I + 16 * mt + 4 * g) = dh2;
+    static_for<KC>([&](auto q) {  // dense_1^T: A[k = 16nt+c][m = 16mt+4g+r] = W1[m][k]
+      constexpr int C0 = decltype(q)::value;
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      if constexpr (C0 + 1 < KC) {
+        st.request_cols(w1T + (size_t)(16 * KT * (C0 + 1)) * I, I, mt);
+      } else {
+        if (mt + 1 < IT) {
+          if (SAVED) st.request(w2T, H, nullptr, I, mt + 1, 0); else st.request(P.w1, H, P.bb1, I, mt + 1, 0);
+        } else {
+          st.request(wdT, H, nullptr, H, 0, 0);
+        }
+      }
+      PIN_ORDER();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nt = 0; nt < KT; ++nt) da[KT * C0 + nt] = mfma16(frag[nt][r], dh2[r], da[KT * C0 + nt]);
+      PIN_ORDER();
+      st.commit();
+    });
+  }
+
+  // ---- through the first LayerNorm: d h1 (in da's registers), d x; then d ctx = d h1 . Wd --------------------------------
+  {
+    auto keep1 = [&](int t) { return row_keep_scale(P.p1, P.keep1, P.seed1 + step, row, 4 * t + g, H); };
+    const float2 st1 = *(const float2*)(S.st1 + 2 * (size_t)row);
+    f4 dz[DT];
+    ln_backward_streamed<DT>(S.h1 + (size_t)row * H, P.x + (size_t)W.src[0] * H, nullptr, da, keep1, P.g1, st1.x, st1.y, ok,
+                             write_part, c, g, dz, part, part ? part + H : nullptr);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      da[t] = dz[t] * keep1(t);  // d h1
+      if (ok) {
+        if (IO.d_x) store_grad(IO.d_x + (size_t)W.src[0] * H + 16 * t + 4 * g, dz[t], P.src_index != nullptr);
+        if (IO.d_h1) *(f4*)(IO.d_h1 + (size_t)row * H + 16 * t + 4 * g) = da[t];
+      }
+    }
+  }
+  // dense^T: A[k = 16nt+c][n = 16t+4g+r] = Wd[n][k] = WdT[16nt+c][16t+4g+r]  (walked also without d_ctx: the barriers)
+  static_for<DT>([&](auto k) {
+    constexpr int NT = decltype(k)::value;
+    f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+    static_for<KC>([&](auto q) {
+      constexpr int C0 = decltype(q)::value;
+      constexpr bool last = NT + 1 == DT && C0 + 1 == KC;
+      f4 frag[KT], b;
+      st.fetch(frag, b);
+      if constexpr (C0 + 1 < KC) st.request(wdT, H, nullptr, H, NT, C0 + 1);
+      else if constexpr (NT + 1 < DT) st.request(wdT, H, nullptr, H, NT + 1, 0);
+      PIN_ORDER();
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r & 1] = mfma16(frag[t][r], da[KT * C0 + t][r], acc[r & 1]);
+      PIN_ORDER();
+      if constexpr (!last) st.commit();
+    });
+    if (IO.d_ctx && ok) store_grad(IO.d_ctx + (size_t)W.src[0] * H + 16 * NT + 4 * g, acc[0] + acc[1], P.src_index != nullptr);
+  });
+}
+
 template <int H, int I>
 int launch_wide_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
   const int blocks = (p.rows + 15) / 16;
   static const bool per_wave = getenv("ACATTN_TAIL_PER_WAVE") != nullptr;  // measurement: the per-wave weight stream
+  static const bool chunked = getenv("ACATTN_TAIL_CHUNKED") != nullptr;    // cross-check: the hidden-256 form at 128
+  if (H > 128 || chunked) {
+    hipLaunchKernelGGL((tail_chunked_fwd_kernel<H, I>), dim3((blocks + NWV - 1) / NWV), dim3(64 * NWV), 0, stream, p, s);
+    return (int)hipGetLastError();
+  }
+  if constexpr (H <= 128) {
   if (wide_split(p.rows))
     hipLaunchKernelGGL((tail_wide_fwd_kernel<H, I, 4>), dim3(blocks), dim3(256), 0, stream, p, s);
   else if (per_wave)
     hipLaunchKernelGGL((tail_wide_fwd_kernel<H, I, 1>), dim3(blocks), dim3(64), 0, stream, p, s);
   else
     hipLaunchKernelGGL((tail_staged_fwd_kernel<H, I>), dim3((blocks + NWV - 1) / NWV), dim3(64 * NWV), 0, stream, p, s);
+  }
   return (int)hipGetLastError();
 }
 
@@ -1198,6 +1531,16 @@ int launch_wide_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, co
   const int blocks = (p.rows + 15) / 16;
   const bool split = wide_split(p.rows);
   static const bool per_wave = getenv("ACATTN_TAIL_PER_WAVE") != nullptr;  // measurement: the per-wave weight stream
+  static const bool chunked = getenv("ACATTN_TAIL_CHUNKED") != nullptr;    // cross-check: the hidden-256 form at 128
+  if (H > 128 || chunked) {
+    const int wgs = (blocks + NWV - 1) / NWV;
+    if (s.gelu_grad)
+      hipLaunchKernelGGL((tail_chunked_bwd_kernel<H, I, true>), dim3(wgs), dim3(64 * NWV), 0, stream, p, s, io, (const float*)ws);
+    else
+      hipLaunchKernelGGL((tail_chunked_bwd_kernel<H, I, false>), dim3(wgs), dim3(64 * NWV), 0, stream, p, s, io, (const float*)ws);
+    return (int)hipGetLastError();
+  }
+  if constexpr (H <= 128) {
   if (!split && !per_wave) {
     const int wgs = (blocks + NWV - 1) / NWV;
     if (s.gelu_grad)
@@ -1216,6 +1559,7 @@ int launch_wide_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, co
       hipLaunchKernelGGL((tail_wide_bwd_kernel<H, I, 4, false>), dim3(blocks), dim3(256), 0, stream, p, s, io, (const float*)ws);
     else
       hipLaunchKernelGGL((tail_wide_bwd_kernel<H, I, 1, false>), dim3(blocks), dim3(64), 0, stream, p, s, io, (const float*)ws);
+  }
   }
   return (int)hipGetLastError();
 }
@@ -1253,7 +1597,7 @@ int launch_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const a
 }  // namespace
 
 bool acattn_tail_supported(int H, int I) {
-  return (H == 64 && (I == 256 || I == 128)) || (H == 128 && (I == 512 || I == 256));
+  return (H == 64 && (I == 256 || I == 128)) || (H == 128 && (I == 512 || I == 256)) || (H == 256 && I == 1024);
 }
 
 int acattn_tail_bwd_partial_rows(int rows) { return (rows + rows_per_wave(rows) - 1) / rows_per_wave(rows); }
@@ -1271,6 +1615,7 @@ int acattn_launch_tail_fwd(const acattn_tail_problem& p, const acattn_tail_saved
   if (p.H == 64 && p.I == 128) return launch_fwd<64, 128>(p, s, stream);
   if (p.H == 128 && p.I == 512) return launch_wide_fwd<128, 512>(p, s, stream);
   if (p.H == 128 && p.I == 256) return launch_wide_fwd<128, 256>(p, s, stream);
+  if (p.H == 256 && p.I == 1024) return launch_wide_fwd<256, 1024>(p, s, stream);
   acattn_set_error("layer tail: unsupported (hidden_size, inner_size)");
   return -1;
 }
@@ -1281,6 +1626,7 @@ int acattn_launch_tail_bwd(const acattn_tail_problem& p, const acattn_tail_saved
   if (p.H == 64 && p.I == 128) return launch_bwd<64, 128>(p, s, io, stream);
   if (p.H == 128 && p.I == 512) return launch_wide_bwd<128, 512>(p, s, io, stream);
   if (p.H == 128 && p.I == 256) return launch_wide_bwd<128, 256>(p, s, io, stream);
+  if (p.H == 256 && p.I == 1024) return launch_wide_bwd<256, 1024>(p, s, io, stream);
   acattn_set_error("layer tail: unsupported (hidden_size, inner_size)");
   return -1;
 }

@@ -27,6 +27,7 @@ from .state import state_of
 
 # measurement switch (bench.py --tail unfused): route supported sizes through the unfused node as well
 FUSED_KERNEL = True
+FUSED_MAX_HIDDEN = 128  # widest hidden size routed to the single-launch node by default (256 is supported, see fused_supported)
 
 
 def _tail_problem(c, x, wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2, eps1, eps2, p1, p2, k1, k2, seed1, seed2, seed_t,
@@ -188,7 +189,12 @@ def supported(att, ffn) -> bool:
 
 def fused_supported(att, ffn) -> bool:
     """The single-launch node covers this (hidden, inner) pair (it can also pick rows itself: layer_tail(pick=...))."""
-    return FUSED_KERNEL and bool(_lib.load().acattn_layer_tail_supported(att.dense.out_features, ffn.dense_1.out_features))
+    H = att.dense.out_features
+    # hidden 256: the launch exists and is parity-tested, but measured slower than the hipBLASLt node on MI355X (one wave
+    # per SIMD: 4.72 against 3.91 ms forward + backward at 102,400 rows; configs[4] 45.6 against 43.1 ms per step)
+    if H > FUSED_MAX_HIDDEN:
+        return False
+    return FUSED_KERNEL and bool(_lib.load().acattn_layer_tail_supported(H, ffn.dense_1.out_features))
 
 
 def layer_tail(ctx_layer, input_tensor, att, ffn, keep_out=None, keep_ffn=None, pick=None):

@@ -93,7 +93,7 @@ def test_validation_errors_without_gpu(lib):
     tp.rows, tp.H, tp.I = 16, 96, 256
     assert lib.acattn_layer_tail_fwd(C.byref(tp), C.byref(ts), None) < 0 and b"hidden_size" in lib.acattn_last_error()
     assert lib.acattn_layer_tail_supported(64, 256) == 1 and lib.acattn_layer_tail_supported(128, 512) == 1
-    assert lib.acattn_layer_tail_supported(256, 1024) == 0 and lib.acattn_layer_tail_supported(96, 256) == 0
+    assert lib.acattn_layer_tail_supported(256, 1024) == 1 and lib.acattn_layer_tail_supported(96, 256) == 0
     assert lib.acattn_layer_tail_bwd_workspace_bytes(128, 512) == 4 * (2 * 128 * 512 + 128 * 128)
     assert lib.acattn_layer_tail_bwd_workspace_bytes(64, 256) == 0 and lib.acattn_layer_tail_bwd_partial_rows_for(100, 128) == 7
     pp, po = _lib.ProjProblem(), _lib.ProjOut()
