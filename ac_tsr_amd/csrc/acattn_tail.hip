@@ -53,6 +53,18 @@ bool split_slabs(int rows) {
   static const int limit = getenv("ACATTN_TAIL_SPLIT_ROWS") ? atoi(getenv("ACATTN_TAIL_SPLIT_ROWS")) : 4096;
   return g_tail_nb == 0 && rows <= limit;
 }
+#ifndef ACATTN_TAIL64_WAVES
+#define ACATTN_TAIL64_WAVES 3
+#endif
+// hidden 64: the staged (weights through LDS) form from this many rows up, unless ACATTN_TAIL_PER_WAVE is set.  Measured
+// (tools/tail_time.py, I = 256): 102,400 rows 119 against 140 us forward, 457 against 501 us forward + backward; at the
+// 25,600 rows of the L = 50 benchmark both take 40 us forward (1,600 row blocks on 1,024 SIMDs: the second block of the
+// busiest SIMD sets the length either way) and the step is 17 us slower with the staged form.
+bool staged64(int rows) {
+  static const bool per_wave = getenv("ACATTN_TAIL_PER_WAVE") != nullptr;
+  static const int from = getenv("ACATTN_TAIL64_STAGED_ROWS") ? atoi(getenv("ACATTN_TAIL64_STAGED_ROWS")) : 32768;
+  return !per_wave && g_tail_nb == 0 && rows >= from;
+}
 // hidden 128 / 256: one row block per wave; four waves per block below this many rows
 bool wide_split(int rows) { return rows <= 8192; }
 int rows_per_wave(int rows) { return split_slabs(rows) ? 16 : 16 * (g_tail_nb ? g_tail_nb : (rows >= 16384 ? 2 : 1)); }
@@ -908,7 +920,8 @@ __device__ __forceinline__ Rows<NB> wg_tail_rows(const acattn_tail_problem& P, i
   return w;
 }
 
-__device__ __forceinline__ void stage_init(WeightStage& st, f4* lds) {
+template <class Stage>
+__device__ __forceinline__ void stage_init(Stage& st, f4* lds) {
   st.lds = lds;
   st.par = 1;  // the first commit fills buffer 0 and flips back to it
   st.lane = threadIdx.x & 63;
@@ -1184,11 +1197,13 @@ __global__ void __launch_bounds__(64 * NWV, 2) tail_staged_bwd_kernel(const acat
 // then gradients; the second walk hits L1 / L2).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int H, int I>
-__global__ void __launch_bounds__(64 * NWV, H > 128 ? 1 : 2) tail_chunked_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
+__global__ void __launch_bounds__(64 * NWV, H > 128 ? 1 : (H < 128 ? ACATTN_TAIL64_WAVES : 2)) tail_chunked_fwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S) {
+  constexpr int KT = H >= 128 ? 8 : 4;  // fragments per staged chunk (shadows the file-level 8)
   constexpr int DT = H / 16, IT = I / 16, KC = DT / KT;
   constexpr float inv_h = 1.0f / H;
-  __shared__ f4 stage_lds[2 * STAGE_F4];
-  WeightStage st;
+  using Stage = WeightStageT<KT>;
+  __shared__ f4 stage_lds[2 * Stage::STAGE_F4];
+  Stage st;
   stage_init(st, stage_lds);
   const int c = st.c, g = st.g;
   const Rows<1> W = wg_tail_rows<1>(P, st.wave);
@@ -1365,11 +1380,13 @@ __device__ __forceinline__ void ln_backward_streamed(const float* zp, const floa
 }
 
 template <int H, int I, bool SAVED>
-__global__ void __launch_bounds__(64 * NWV, H > 128 ? 1 : 2) tail_chunked_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
+__global__ void __launch_bounds__(64 * NWV, H > 128 ? 1 : (H < 128 ? ACATTN_TAIL64_WAVES : 2)) tail_chunked_bwd_kernel(const acattn_tail_problem P, const acattn_tail_saved S,
                                                                        const acattn_tail_bwd_io IO, const float* __restrict__ ws) {
+  constexpr int KT = H >= 128 ? 8 : 4;  // fragments per staged chunk (shadows the file-level 8)
   constexpr int DT = H / 16, IT = I / 16, KC = DT / KT;
-  __shared__ f4 stage_lds[2 * STAGE_F4];
-  WeightStage st;
+  using Stage = WeightStageT<KT>;
+  __shared__ f4 stage_lds[2 * Stage::STAGE_F4];
+  Stage st;
   stage_init(st, stage_lds);
   const int c = st.c, g = st.g;
   const Rows<1> W = wg_tail_rows<1>(P, st.wave);
@@ -1566,6 +1583,11 @@ int launch_wide_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, co
 
 template <int H, int I>
 int launch_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStream_t stream) {
+  if (staged64(p.rows)) {
+    const int wgs = (p.rows + 16 * NWV - 1) / (16 * NWV);
+    hipLaunchKernelGGL((tail_chunked_fwd_kernel<H, I>), dim3(wgs), dim3(64 * NWV), 0, stream, p, s);
+    return (int)hipGetLastError();
+  }
   const int nb = rows_per_wave(p.rows) / 16;
   const int blocks = (p.rows + 16 * nb - 1) / (16 * nb);
   if (nb == 1 && split_slabs(p.rows)) {
@@ -1581,6 +1603,20 @@ int launch_fwd(const acattn_tail_problem& p, const acattn_tail_saved& s, hipStre
 
 template <int H, int I>
 int launch_bwd(const acattn_tail_problem& p, const acattn_tail_saved& s, const acattn_tail_bwd_io& io, hipStream_t stream) {
+  if (staged64(p.rows)) {
+    if (!io.workspace) {
+      acattn_set_error("layer tail backward: this row count needs acattn_tail_bwd_io.workspace (acattn_layer_tail_bwd_workspace_bytes)");
+      return -1;
+    }
+    float* ws = (float*)io.workspace;
+    hipLaunchKernelGGL(tail_transpose_kernel, dim3(I / 16, I / 16, 3), dim3(256), 0, stream, p.w1, p.w2, p.wd, H, I, ws);
+    const int wgs = (p.rows + 16 * NWV - 1) / (16 * NWV);
+    if (s.gelu_grad)
+      hipLaunchKernelGGL((tail_chunked_bwd_kernel<H, I, true>), dim3(wgs), dim3(64 * NWV), 0, stream, p, s, io, (const float*)ws);
+    else
+      hipLaunchKernelGGL((tail_chunked_bwd_kernel<H, I, false>), dim3(wgs), dim3(64 * NWV), 0, stream, p, s, io, (const float*)ws);
+    return (int)hipGetLastError();
+  }
   const int nb = rows_per_wave(p.rows) / 16;
   const int blocks = acattn_tail_bwd_partial_rows(p.rows);
   if (nb == 1 && split_slabs(p.rows)) {
@@ -1601,8 +1637,11 @@ bool acattn_tail_supported(int H, int I) {
 }
 
 int acattn_tail_bwd_partial_rows(int rows) { return (rows + rows_per_wave(rows) - 1) / rows_per_wave(rows); }
-int acattn_tail_bwd_partial_rows_h(int rows, int H) { return H > 64 ? (rows + 15) / 16 : acattn_tail_bwd_partial_rows(rows); }
-int64_t acattn_tail_bwd_ws_bytes(int H, int I) { return H > 64 ? ((int64_t)2 * H * I + (int64_t)H * H) * (int64_t)sizeof(float) : 0; }
+int acattn_tail_bwd_partial_rows_h(int rows, int H) {
+  return (H > 64 || staged64(rows)) ? (rows + 15) / 16 : acattn_tail_bwd_partial_rows(rows);
+}
+// (hidden 64 needs it for the staged form only, i.e. above the slab-split row count; asking for it always is simpler)
+int64_t acattn_tail_bwd_ws_bytes(int H, int I) { return ((int64_t)2 * H * I + (int64_t)H * H) * (int64_t)sizeof(float); }
 
 int acattn_select_tail_nb(int nb) {
   const int prev = g_tail_nb;

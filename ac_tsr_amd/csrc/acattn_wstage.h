@@ -28,9 +28,15 @@ __device__ __forceinline__ f4 bias_tile(const float* bias, int n_out, int nt, in
 #define ACATTN_PROJ_NWV 4
 #endif
 constexpr int NWV = ACATTN_PROJ_NWV;   // waves per workgroup
-constexpr int STAGE_F4 = KT * 64 + 4;  // one chunk (KT fragments x 64 lanes) + the tile's bias (4 float4, one per lane group)
+// one chunk (KTV fragments x 64 lanes) + the tile's bias (4 float4, one per lane group)
+template <int KTV>
+constexpr int stage_f4() { return KTV * 64 + 4; }
+constexpr int STAGE_F4 = stage_f4<KT>();
 
-struct WeightStage {
+// KTV = fragments per chunk: 8 (128 inputs) for hidden 128 / 256, 4 for the hidden-64 layer tail
+template <int KTV>
+struct WeightStageT {
+  static constexpr int KT = KTV, STAGE_F4 = stage_f4<KTV>();
   f4* lds;  // [2][STAGE_F4]
   int par;  // buffer the NEXT fetch reads
   int wave, lane, c, g;
@@ -67,5 +73,7 @@ struct WeightStage {
     b = src[KT * 64 + g];
   }
 };
+
+using WeightStage = WeightStageT<8>;
 
 }  // namespace

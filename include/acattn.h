@@ -361,8 +361,8 @@ typedef struct acattn_tail_bwd_io {
   float* dgb_part;     /* [acattn_layer_tail_bwd_partial_rows(rows), 4, H] partial sums of (dgamma1, dbeta1, dgamma2,
                           dbeta2), to be summed over the leading dimension by the caller; or NULL.  Hidden 128 / 256:
                           acattn_layer_tail_bwd_partial_rows_for(rows, H) rows */
-  void* workspace;     /* ABI 26: device scratch of acattn_layer_tail_bwd_workspace_bytes(H, I) bytes (0 at hidden 64: may
-                          be NULL there); hidden 128 / 256 keep transposed weight copies in it during the launch */
+  void* workspace;     /* ABI 26: device scratch of acattn_layer_tail_bwd_workspace_bytes(H, I) bytes: transposed weight
+                          copies live in it during the launch (every width but hidden 64 at <= 4096 rows needs it) */
 } acattn_tail_bwd_io;
 
 int acattn_layer_tail_supported(int32_t H, int32_t I);

@@ -95,7 +95,8 @@ def test_validation_errors_without_gpu(lib):
     assert lib.acattn_layer_tail_supported(64, 256) == 1 and lib.acattn_layer_tail_supported(128, 512) == 1
     assert lib.acattn_layer_tail_supported(256, 1024) == 1 and lib.acattn_layer_tail_supported(96, 256) == 0
     assert lib.acattn_layer_tail_bwd_workspace_bytes(128, 512) == 4 * (2 * 128 * 512 + 128 * 128)
-    assert lib.acattn_layer_tail_bwd_workspace_bytes(64, 256) == 0 and lib.acattn_layer_tail_bwd_partial_rows_for(100, 128) == 7
+    assert lib.acattn_layer_tail_bwd_workspace_bytes(64, 256) == 4 * (2 * 64 * 256 + 64 * 64)
+    assert lib.acattn_layer_tail_bwd_partial_rows_for(100, 128) == 7 and lib.acattn_layer_tail_bwd_partial_rows_for(102400, 64) == 6400
     pp, po = _lib.ProjProblem(), _lib.ProjOut()
     pp.rows, pp.H, pp.G = 16, 64, 300
     assert lib.acattn_projections_fwd(C.byref(pp), C.byref(po), None) < 0 and b"gate" in lib.acattn_last_error()

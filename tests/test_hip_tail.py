@@ -44,7 +44,7 @@ def _apply(node, dev, eps, p, keep1, keep2, seed1, seed2, state):
 
 # hidden 128 [round 3]: the streamed-weight kernels (BASELINE configs[3]: H = 128, inner 512); four waves per row block
 # up to 8192 rows, one above
-@pytest.mark.parametrize("rows,I,H", [(512, 256, 64), (37, 256, 64), (16384 + 21, 256, 64), (100, 128, 64),
+@pytest.mark.parametrize("rows,I,H", [(512, 256, 64), (37, 256, 64), (16384 + 21, 256, 64), (100, 128, 64), (32768 + 21, 256, 64), (40000, 128, 64),
                                       (512, 512, 128), (37, 512, 128), (8192 + 21, 512, 128), (100, 256, 128), (20000, 256, 128),
                                       (512, 1024, 256), (37, 1024, 256), (4117, 1024, 256)])
 @pytest.mark.parametrize("p", [0.0, 0.5])
@@ -72,7 +72,7 @@ def test_fused_tail_matches_fp64_chain(rows, I, p, H):
     assert torch.equal(gc, got[0]) and torch.equal(gx, got[1])
 
 
-@pytest.mark.parametrize("rows,H,I", [(512, 64, 256), (25600, 64, 256), (512, 128, 512), (25600, 128, 512), (6000, 256, 1024)])
+@pytest.mark.parametrize("rows,H,I", [(512, 64, 256), (25600, 64, 256), (51200, 64, 256), (512, 128, 512), (25600, 128, 512), (6000, 256, 1024)])
 def test_fused_tail_counter_dropout_equals_unfused_node(rows, H, I):
     """In-kernel dropout: the fused launch and the unfused node draw the same keep decisions from the same seeds, so
     outputs and gradients agree to rounding; a different seed changes the output."""
