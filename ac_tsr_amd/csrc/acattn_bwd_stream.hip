@@ -990,6 +990,7 @@ int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, b
     case 16: return launch_onerow<16>(p, io, accumulate, stream);
     case 32: return launch_onerow<32>(p, io, accumulate, stream);
     case 64: return launch_onerow<64>(p, io, accumulate, stream);
+    case 128: return launch_onerow<128>(p, io, accumulate, stream);  // [r3]
   }
   return -100;
 }
@@ -1006,6 +1007,7 @@ int acattn_launch_bwd_stream(const acattn_problem& p, const acattn_bwd_io& io, h
     case 16: return launch_stream<16>(p, io, ws, stream);
     case 32: return launch_stream<32>(p, io, ws, stream);
     case 64: return launch_stream<64>(p, io, ws, stream);
+    case 128: return launch_stream<128>(p, io, ws, stream);  // [r3]
   }
   return -100;
 }

@@ -6,6 +6,7 @@
 int acattn_launch_fwd_stream_dh16(const acattn_problem& p, const acattn_fwd_out& o, int pre, hipStream_t stream);
 int acattn_launch_fwd_stream_dh32(const acattn_problem& p, const acattn_fwd_out& o, int pre, hipStream_t stream);
 int acattn_launch_fwd_stream_dh64(const acattn_problem& p, const acattn_fwd_out& o, int pre, hipStream_t stream);
+int acattn_launch_fwd_stream_dh128(const acattn_problem& p, const acattn_fwd_out& o, int pre, hipStream_t stream);
 
 // Returns -100 when the problem is outside this kernel's domain (the caller then tries the other kernels).
 int acattn_launch_fwd_stream(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
@@ -29,6 +30,7 @@ int acattn_launch_fwd_stream(const acattn_problem& p, const acattn_fwd_out& o, h
     case 16: return acattn_launch_fwd_stream_dh16(p, o, pre, stream);
     case 32: return acattn_launch_fwd_stream_dh32(p, o, pre, stream);
     case 64: return acattn_launch_fwd_stream_dh64(p, o, pre, stream);
+    case 128: return acattn_launch_fwd_stream_dh128(p, o, pre, stream);  // [r3] one wave per SIMD, spill-free
   }
   return -100;
 }

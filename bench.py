@@ -75,11 +75,12 @@ def parse():
     if a.config == "cfg4":  # "Yelp-scale synthetic, L=200 d=128 4 heads"; the catalogue size is ours (stated in the line)
         a.seq_len, a.hidden, a.heads, a.inner = 200, 128, 4, 512
     elif a.config == "cfg5":  # "AC-BERT4Rec variant (bidirectional mask) L=200 d=256"
-        # heads: BASELINE leaves them open; 4 -> head size 64 (the reference default of 2 would need head size 128,
-        # which the tuned kernels do not cover).  20,000 items by default: the masked-slot CE at d=256 goes through
+        # heads: BASELINE leaves them open; 4 -> head size 64 (the reference default of 2 is head size 128: since round 3
+        # the streaming kernels cover it, one wave per SIMD).  20,000 items by default: the masked-slot CE at d=256 goes through
         # materialised [rows, N] logits (measured faster than the fused kernels at this width, model.py) and ~20 k rows x
         # 100 k items are 8 GB per logits tensor; `--items 100000` runs that too.
-        a.seq_len, a.hidden, a.heads, a.inner, a.model = 200, 256, 4, 1024, "AcBERT4Rec"
+        heads = a.heads if "--heads" in sys.argv else 4  # `--config cfg5 --heads 2`: the reference default (head size 128)
+        a.seq_len, a.hidden, a.heads, a.inner, a.model = 200, 256, heads, 1024, "AcBERT4Rec"
         a.items = a.items or 20000
     a.items = a.items or 100000
     return a

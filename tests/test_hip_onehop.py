@@ -64,8 +64,9 @@ def _affine_planes(t, nh):
     return planes.float()
 
 
-@pytest.mark.parametrize("B,L,H,nh,causal", [(512, 50, 64, 2, True), (512, 50, 64, 2, False), (8, 200, 128, 4, True)],
-                         ids=["bench_shape", "bench_shape_bidirectional", "cfg4_shape"])
+@pytest.mark.parametrize("B,L,H,nh,causal", [(512, 50, 64, 2, True), (512, 50, 64, 2, False), (8, 200, 128, 4, True),
+                                             (4, 200, 256, 2, False), (6, 50, 256, 2, True)],
+                         ids=["bench_shape", "bench_shape_bidirectional", "cfg4_shape", "dh128_L200_bidirectional", "dh128_L50"])
 @pytest.mark.parametrize("extras", [False, True], ids=["in_kernel", "producer_extras"])
 def test_streaming_forward_matches_oracle_in_one_hop(B, L, H, nh, causal, extras):
     t, kv, lens, g = _problem(B, L, H, nh, seed=101, causal=causal)
@@ -99,7 +100,8 @@ def test_streaming_forward_matches_oracle_in_one_hop(B, L, H, nh, causal, extras
 
 
 @pytest.mark.parametrize("pattern", ["all", "calibrated_read_row", "attacked_read_row_plus_mask"])
-@pytest.mark.parametrize("B,L,H,nh", [(512, 50, 64, 2), (8, 200, 128, 4)], ids=["bench_shape", "cfg4_shape"])
+@pytest.mark.parametrize("B,L,H,nh", [(512, 50, 64, 2), (8, 200, 128, 4), (3, 200, 256, 2), (5, 50, 256, 2)],
+                         ids=["bench_shape", "cfg4_shape", "dh128_L200", "dh128_L50"])
 def test_tuned_backward_matches_oracle_autograd_in_one_hop(B, L, H, nh, pattern):
     """`all`: every cotangent dense (the first layer's calibrated pass; row-resident kernel at L = 50, the streaming
     pair at L = 200).  `calibrated_read_row`: one context row per sequence (the last layer, pass 1: one-row kernel).
