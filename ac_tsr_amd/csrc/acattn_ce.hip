@@ -582,7 +582,7 @@ template <int CH>
 int pick_tiles(int N) {
   const int per_tile = num_cus() * CE_NW * 16;
   const int need = (N + per_tile - 1) / per_tile;
-  if (CH <= 64) return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
+  if (CH <= 64) return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 6 ? 6 : 7;
   if (CH > 128) return 1;
   return need <= 1 ? 1 : need <= 2 ? 2 : 3;
 }
@@ -592,7 +592,7 @@ int pick_tiles(int N) {
 template <int CH>
 int pick_tiles_fwd(int N) {
   static const int forced = getenv("ACATTN_CE_TILES_FWD") ? atoi(getenv("ACATTN_CE_TILES_FWD")) : 0;  // measurements
-  if (forced == 1 || forced == 2 || forced == 4 || forced == 7) return forced;
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 6 || forced == 7) return forced;
   return pick_tiles<CH>(N);
 }
 
@@ -663,6 +663,7 @@ int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_
     case 2: return launch_fwd_dir_t<CH, 2>(p, ws, lse, row_loss, dir, stream);
     case 3: return launch_fwd_dir_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, dir, stream);
     case 4: return launch_fwd_dir_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, dir, stream);
+    case 6: return launch_fwd_dir_t<CH, (CH <= 64 ? 6 : 3)>(p, ws, lse, row_loss, dir, stream);
     default: return launch_fwd_dir_t<CH, max_tiles<CH>()>(p, ws, lse, row_loss, dir, stream);
   }
 }
@@ -695,6 +696,7 @@ int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss
     case 2: return launch_fwd_t<CH, 2>(p, ws, lse, row_loss, stream);
     case 3: return launch_fwd_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, stream);
     case 4: return launch_fwd_t<CH, (CH <= 64 ? 4 : 3)>(p, ws, lse, row_loss, stream);
+    case 6: return launch_fwd_t<CH, (CH <= 64 ? 6 : 3)>(p, ws, lse, row_loss, stream);
     default: return launch_fwd_t<CH, max_tiles<CH>()>(p, ws, lse, row_loss, stream);
   }
 }
@@ -709,6 +711,7 @@ int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, 
     case 2: return launch_bwd_t<CH, 2>(p, lse, coef, ws, d_out, d_table, stream);
     case 3: return launch_bwd_t<CH, (CH <= 64 ? 4 : 3)>(p, lse, coef, ws, d_out, d_table, stream);
     case 4: return launch_bwd_t<CH, (CH <= 64 ? 4 : 3)>(p, lse, coef, ws, d_out, d_table, stream);
+    case 6: return launch_bwd_t<CH, (CH <= 64 ? 6 : 3)>(p, lse, coef, ws, d_out, d_table, stream);
     default: return launch_bwd_t<CH, max_tiles<CH>()>(p, lse, coef, ws, d_out, d_table, stream);
   }
 }
