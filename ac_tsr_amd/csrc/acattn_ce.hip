@@ -38,8 +38,14 @@ struct CeCfg {
 // ---------------------------------------------------------------------------------------------------------
 // forward: per (row, wave) partial (max, sum exp) of the wave's items
 // ---------------------------------------------------------------------------------------------------------
-template <int CH, int NTILES>
-__global__ void __launch_bounds__(64 * CE_NW) ce_fwd_kernel(const acattn_ce_problem P, float2* __restrict__ part) {
+// SPLIT [round 3]: the grid covers gridDim.x * CE_NW * ITEMS items (a whole number of NTILES-tile waves, fewer than N) and
+// the n_left 16-item tiles behind them are LEFTOVER tiles: workgroup l < n_left also takes leftover tile l, its four
+// waves a quarter of the batch sweep each, after their own sweep.  100,000 items are 6,250 tiles = 1,024 waves x 6 + 106:
+// with seven tiles per wave (224 workgroups) every launch lasts seven tiles' sweep, with six + a quarter sweep of one
+// more tile for 106 workgroups 6.25.  The leftover tile's results are separate partials / slabs behind the regular ones
+// (one writer per row: the waves' row blocks are disjoint), so nothing is read back or accumulated in place.
+template <int CH, int NTILES, bool SPLIT = false>
+__global__ void __launch_bounds__(64 * CE_NW) ce_fwd_kernel(const acattn_ce_problem P, float2* __restrict__ part, int n_left = 0) {
   using C = CeCfg<CH, NTILES>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -121,6 +127,65 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_fwd_kernel(const acattn_ce_prob
       for (int s = 0; s < C::KS; ++s) hf[s] = hn[s];
     }
   }
+  if constexpr (SPLIT) {
+    // leftover units (tile, row block), n_left * nrb of them, dealt out evenly: wave w takes units [w U, (w + 1) U)
+    const int n_units = n_left * nrb, U = (n_units + gridDim.x * CE_NW - 1) / (gridDim.x * CE_NW);
+    const int first = wid * U, n_my = min(max(n_units - first, 0), U);
+    int cur_tile = -1;
+    float ex[C::KS];
+    auto load_tile = [&](int tile) {
+      const int itx = gridDim.x * CE_NW * C::ITEMS + 16 * tile;
+#pragma unroll
+      for (int s4 = 0; s4 < C::KS / 4; ++s4) {
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (itx + c < N) v = *(const f4*)(P.table + (size_t)(itx + c) * CH + C::KS * g + 4 * s4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ex[4 * s4 + e] = v[e];
+      }
+    };
+    if (n_my > 0) {  // (requested together with the first units' rows, not after them)
+      cur_tile = first / nrb;
+      load_tile(cur_tile);
+    }
+    constexpr int GU = 4;  // units whose batch rows are requested together: a unit is too short to cover the next one's round trip
+    for (int k0 = 0; k0 < n_my; k0 += GU) {
+      float hx[GU][C::KS];
+#pragma unroll
+      for (int q = 0; q < GU; ++q)
+        if (k0 + q < n_my) load_rows((first + k0 + q) % nrb, hx[q]);
+#pragma unroll
+      for (int q = 0; q < GU; ++q) {
+        if (k0 + q >= n_my) break;
+        const int u = first + k0 + q, tile = u / nrb, rb = u - tile * nrb;
+        const int itx = gridDim.x * CE_NW * C::ITEMS + 16 * tile;  // first item of the leftover tile
+        if (tile != cur_tile) {  // (uniform per wave)
+          cur_tile = tile;
+          load_tile(tile);
+        }
+        f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int s = 0; s < C::KS; s += 2) {
+          a0 = mfma16(ex[s], hx[q][s], a0);
+          a1 = mfma16(ex[s + 1], hx[q][s + 1], a1);
+        }
+        f4 acc = a0 + a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (itx + 4 * g + r >= N) acc[r] = ACATTN_NEG_INF;
+        const float m = quad_max(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+        float sum = 0.f;
+        if (m > ACATTN_NEG_INF) {
+          f4 x = acc * kLog2e - m * kLog2e;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+          sum = (x[0] + x[1]) + (x[2] + x[3]);
+        }
+        sum = quad_sum(sum);
+        const int row = 16 * rb + c;
+        if (g == 0 && row < B) part[(size_t)(gridDim.x * CE_NW + tile) * B + row] = float2{m, sum};
+      }
+    }
+  }
 }
 
 // one wave per batch row: fold the partials, add the target logit
@@ -192,13 +257,13 @@ __device__ unsigned long long g_ce_stamps[4096 * 8];
 // maximum when their [16, CH] tiles are folded, and the workgroup emits (max, sum-exp) per row next to its slab of
 // sum_n exp(l_n - max) E_n; ce_dir_reduce_kernel finishes the soft-max across workgroups (flash-attention with
 // K = V = the item table).  `lse` / `coef` are unused then, `part` receives the (max, sum-exp) pairs.
-template <int CH, int NTILES, bool WITH_TABLE_GRAD, bool DIR = false>
+template <int CH, int NTILES, bool WITH_TABLE_GRAD, bool DIR = false, bool SPLIT = false>
 __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_problem P, const float* __restrict__ lse,
                                                             const float* __restrict__ coef,
                                                             float* __restrict__ d_out,
                                                             float* __restrict__ d_out_slab,
                                                             float* __restrict__ d_table,
-                                                            float2* __restrict__ part = nullptr) {
+                                                            float2* __restrict__ part = nullptr, int n_left = 0) {
   static_assert(!(DIR && WITH_TABLE_GRAD), "the forward-with-direction sweep has no table gradient");
   using C = CeCfg<CH, NTILES>;
   constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);  // transpose-scratch row stride: 16 * odd -> conflict-free column reads
@@ -463,6 +528,168 @@ __global__ void __launch_bounds__(64 * CE_NW) ce_bwd_kernel(const acattn_ce_prob
         }
       }
   }
+  if constexpr (SPLIT) {
+    // Leftover units (tile, row block), see ce_fwd_kernel.  Without a table gradient they are dealt out evenly over all
+    // waves; with one, workgroup l < n_left takes ALL of tile l (its waves every fourth row block), so that the tile's
+    // d_table rows are summed inside the workgroup.  Every wave works on its own: its table-row area in LDS is free now and
+    // holds the tile's rows, the wave's batch rows and its transpose scratch; no workgroup barrier inside the sweep.
+    // Results: slab / partial number gridDim.x + tile.
+    const int wid = blockIdx.x * CE_NW + wave;
+    int first, stride, n_my;
+    if (WITH_TABLE_GRAD) {
+      first = blockIdx.x * nrb + wave;
+      stride = CE_NW;
+      n_my = (int)blockIdx.x < n_left ? (nrb - wave + CE_NW - 1) / CE_NW : 0;
+      if ((int)blockIdx.x < n_left) __syncthreads();  // (uniform per workgroup) the last fold has read the exchange areas
+    } else {
+      const int n_units = n_left * nrb, U = (n_units + gridDim.x * CE_NW - 1) / (gridDim.x * CE_NW);
+      first = wid * U;
+      stride = 1;
+      n_my = min(max(n_units - first, 0), U);
+    }
+    constexpr int TSX = 48;  // 16 * odd
+    static_assert(C::ITEMS * C::ES >= 32 * C::ES + 16 * TSX, "the wave's table-row area holds the leftover tile's working set");
+    float* Ex = Es;                 // [16][ES] the leftover tile's table rows
+    float* Hx = Es + 16 * C::ES;    // [16][ES] this wave's batch rows
+    float* Xx = Hx + 16 * C::ES;    // [16][TSX] transpose scratch
+    f4 dEx[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) dEx[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    // a unit is too short to cover the next one's round trip: rows, lse, coef and target of FOUR units are requested together
+    constexpr int HX = 16 * (CH / 4) / 64;  // float4s of a [16, CH] block per lane
+    constexpr int GU = 4;
+    f4 hx_g[GU][HX];
+    float lse_g[GU], cf_g[GU];
+    int tgt_g[GU];
+    auto prefetch_x = [&](int q, int rb) {
+#pragma unroll
+      for (int u = 0; u < HX; ++u) {
+        const int idx = lane + 64 * u;
+        const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+        hx_g[q][u] = f4{0.f, 0.f, 0.f, 0.f};
+        if (16 * rb + r < B) hx_g[q][u] = *(const f4*)(P.out + (size_t)(16 * rb + r) * CH + 4 * c4);
+      }
+      const int row = 16 * rb + c;
+      const bool ok = row < B;
+      lse_g[q] = (ok && !DIR) ? lse[row] : 0.f;
+      cf_g[q] = (ok && !DIR) ? coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f) : 0.f;
+      tgt_g[q] = ok ? (int)P.target[row] : -1;
+    };
+    int cur_tile = -1;
+    for (int k0 = 0; k0 < n_my; k0 += GU) {
+#pragma unroll
+      for (int q = 0; q < GU; ++q)
+        if (k0 + q < n_my) prefetch_x(q, (first + (k0 + q) * stride) % nrb);
+#pragma unroll
+      for (int q = 0; q < GU; ++q) {
+      if (k0 + q >= n_my) break;
+      const int u = first + (k0 + q) * stride, tile = u / nrb, rb = u - tile * nrb;
+      const int itx = gridDim.x * CE_NW * C::ITEMS + 16 * tile;
+      const size_t vslab = (size_t)(gridDim.x + tile) * B;  // row offset of this tile's slab / partials
+      if (tile != cur_tile) {  // (uniform per wave)
+        cur_tile = tile;
+        for (int idx = lane; idx < 16 * (CH / 4); idx += 64) {
+          const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (itx + r < N) v = *(const f4*)(P.table + (size_t)(itx + r) * CH + 4 * c4);
+          *(f4*)(Ex + r * C::ES + 4 * c4) = v;
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < HX; ++w) {
+        const int idx = lane + 64 * w;
+        const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+        *(f4*)(Hx + r * C::ES + 4 * c4) = hx_g[q][w];
+      }
+      const int row = 16 * rb + c;
+      const bool ok = row < B;
+      const float l2 = lse_g[q] * kLog2e;
+      const float cf = cf_g[q];
+      const int tgt = ok ? tgt_g[q] - itx : -1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float hf[C::KS];
+#pragma unroll
+      for (int s4 = 0; s4 < C::KS / 4; ++s4) {
+        const f4 v = *(const f4*)(Hx + c * C::ES + C::KS * g + 4 * s4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hf[4 * s4 + e] = v[e];
+      }
+      f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+      for (int s4 = 0; s4 < C::KS / 4; ++s4) {
+        const f4 e4 = *(const f4*)(Ex + c * C::ES + C::KS * g + 4 * s4);
+        a0 = mfma16(e4[0], hf[4 * s4 + 0], a0);
+        a1 = mfma16(e4[1], hf[4 * s4 + 1], a1);
+        a0 = mfma16(e4[2], hf[4 * s4 + 2], a0);
+        a1 = mfma16(e4[3], hf[4 * s4 + 3], a1);
+      }
+      f4 dlx = a0 + a1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (itx + 4 * g + r >= N) dlx[r] = ACATTN_NEG_INF;
+      float m_w = ACATTN_NEG_INF, s_w = 0.f;
+      if (DIR) {
+        m_w = quad_max(fmaxf(fmaxf(dlx[0], dlx[1]), fmaxf(dlx[2], dlx[3])));
+        const float m2 = m_w > ACATTN_NEG_INF ? m_w * kLog2e : 0.f;
+        f4 x = dlx * kLog2e - m2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+        dlx = x;
+        s_w = quad_sum((x[0] + x[1]) + (x[2] + x[3]));
+      } else {
+        f4 x = dlx * kLog2e - l2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+        if (tgt >= 0 && tgt < 16 && ((tgt >> 2) & 3) == g) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] -= (r == (tgt & 3)) ? 1.0f : 0.0f;
+        }
+        dlx = x * cf;
+      }
+      // d out^T (the tile's 16 items) = E^T . dl^T
+      f4 dh[C::DT];
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) dh[dt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* ep = Ex + (4 * g + kk) * C::ES + c;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) dh[dt] = mfma16(ep[16 * dt], dlx[kk], dh[dt]);
+      }
+      if (ok) {
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) *(f4*)(d_out_slab + (vslab + row) * CH + 16 * dt + 4 * g) = dh[dt];
+        if (DIR && g == 0) part[vslab + row] = float2{m_w, s_w};
+      }
+      if (WITH_TABLE_GRAD) {
+        *(f4*)(Xx + c * TSX + 4 * g) = dlx;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sr = 0; sr < 4; ++sr) {
+          const float at = Xx[(4 * sr + g) * TSX + c];
+#pragma unroll
+          for (int dt = 0; dt < C::DT; ++dt) dEx[dt] = mfma16(at, Hx[(4 * sr + g) * C::ES + 16 * dt + c], dEx[dt]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      }
+    }
+    if (WITH_TABLE_GRAD && (int)blockIdx.x < n_left) {  // the four waves' shares of the tile's d_table rows meet in the exchange areas
+      const int itx = gridDim.x * CE_NW * C::ITEMS + 16 * blockIdx.x;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xw[(4 * g + r) * C::ES + 16 * dt + c] = dEx[dt][r];
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 16 * CH; idx += blockDim.x) {
+        const int i = idx / CH, hcol = idx - i * CH;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < CE_NW; ++w) v += X[w * XS + i * C::ES + hcol];
+        if (itx + i < N) d_table[(size_t)(itx + i) * CH + hcol] = v;
+      }
+    }
+  }
 }
 
 // d_out[i] = sum over workgroups of slab[wg][i]: 32 outputs per workgroup, 8 threads per output (each sums every
@@ -596,6 +823,20 @@ int pick_tiles_fwd(int N) {
   return pick_tiles<CH>(N);
 }
 
+// The split scheme (ce_fwd_kernel): six tiles per wave on every CU + at most one leftover tile per workgroup.  Hidden 64
+// and catalogues whose tile count is 6.x rounds of (CUs x 4 waves): the benchmark's 100,000 items -> 256 workgroups + 106
+// leftover tiles.  ACATTN_CE_SPLIT=0 switches it off (measurement).
+template <int CH>
+bool split_plan(int N, int& n_wg, int& n_left) {
+  static const bool off = getenv("ACATTN_CE_SPLIT") && atoi(getenv("ACATTN_CE_SPLIT")) == 0;
+  if (CH != 64 || off) return false;
+  const int tiles = (N + 15) / 16, per_round = num_cus() * CE_NW;
+  if (tiles / per_round != 6) return false;
+  n_wg = num_cus();
+  n_left = tiles - 6 * per_round;
+  return n_left > 0 && n_left <= n_wg;
+}
+
 template <int CH, int NTILES>
 int launch_fwd_t(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
   using C = CeCfg<CH, NTILES>;
@@ -622,11 +863,11 @@ int launch_bwd_t(const acattn_ce_problem& p, const float* lse, const float* coef
   if (d_table) {
     auto k = ce_bwd_kernel<CH, NTILES, true>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr, 0);
   } else {
     auto k = ce_bwd_kernel<CH, NTILES, false>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr, 0);
   }
   if (slab)
     hipLaunchKernelGGL(ce_bwd_reduce_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, stream, slab, n_wg, n_out,
@@ -647,7 +888,7 @@ int launch_fwd_dir_t(const acattn_ce_problem& p, void* ws, float* lse, float* ro
   float2* part = (float2*)(slab + (size_t)n_wg * n_out);
   auto k = ce_bwd_kernel<CH, NTILES, false, true>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, slab, (float*)nullptr, part);
+  hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, slab, (float*)nullptr, part, 0);
   const size_t rlds = (size_t)(n_wg + (256 / (CH / 4)) * CH) * sizeof(float);
   hipLaunchKernelGGL((ce_dir_reduce_kernel<CH>), dim3(p.B), dim3(256), rlds, stream, p, (const float2*)part,
                      (const float*)slab, n_wg, lse, row_loss, dir);
@@ -656,6 +897,27 @@ int launch_fwd_dir_t(const acattn_ce_problem& p, void* ws, float* lse, float* ro
 
 template <int CH>
 int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, float* dir, hipStream_t stream) {
+  if constexpr (CH == 64) {
+    int n_wg, n_left;
+    const int64_t n_out = (int64_t)p.B * CH;
+    if (split_plan<CH>(p.N, n_wg, n_left) && (n_wg + n_left) * n_out * (int64_t)sizeof(float) <= kSlabLimit) {
+      using C = CeCfg<CH, 6>;
+      constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);
+      constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
+      const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
+      const int n_slabs = n_wg + n_left;
+      float* slab = (float*)ws;
+      float2* part = (float2*)(slab + (size_t)n_slabs * n_out);
+      auto k = ce_bwd_kernel<CH, 6, false, true, true>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, (const float*)nullptr, (const float*)nullptr,
+                         (float*)nullptr, slab, (float*)nullptr, part, n_left);
+      const size_t rlds = (size_t)(n_slabs + (256 / (CH / 4)) * CH) * sizeof(float);
+      hipLaunchKernelGGL((ce_dir_reduce_kernel<CH>), dim3(p.B), dim3(256), rlds, stream, p, (const float2*)part,
+                         (const float*)slab, n_slabs, lse, row_loss, dir);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (CH > 128) return launch_fwd_dir_t<CH, 1>(p, ws, lse, row_loss, dir, stream);
   else
   switch (pick_tiles<CH>(p.N)) {
@@ -670,6 +932,18 @@ int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_
 
 template <int CH>
 int64_t ws_bytes(const acattn_ce_problem& p) {
+  if constexpr (CH == 64) {
+    int n_wg, n_left;
+    if (split_plan<CH>(p.N, n_wg, n_left)) {  // (sized for both forms: the slab limit may send a launch to the other one)
+      const int64_t fwd = (int64_t)(n_wg * CE_NW + n_left) * p.B * (int64_t)sizeof(float2);
+      const int64_t bwd = (int64_t)(n_wg + n_left) * p.B * CH * (int64_t)sizeof(float);
+      const int64_t dirb = bwd + (int64_t)(n_wg + n_left) * p.B * (int64_t)sizeof(float2);
+      const int64_t regular_wg = (p.N + CE_NW * 16 * 7 - 1) / (CE_NW * 16 * 7);
+      const int64_t regular = std::max(regular_wg * CE_NW * p.B * (int64_t)sizeof(float2),
+                                       regular_wg * p.B * (CH * (int64_t)sizeof(float) + (int64_t)sizeof(float2)));
+      return std::max(std::max(fwd, regular), dirb <= kSlabLimit ? dirb : bwd <= kSlabLimit ? bwd : 0);
+    }
+  }
   // forward partials: one (max, sum-exp) pair per (wave, row)
   int tiles = pick_tiles<CH>(p.N);
   if (CH <= 64 && tiles == 3) tiles = 4;
@@ -689,6 +963,15 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
 
 template <int CH>
 int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
+  if constexpr (CH == 64) {
+    int n_wg, n_left;
+    if (split_plan<CH>(p.N, n_wg, n_left)) {
+      hipLaunchKernelGGL((ce_fwd_kernel<CH, 6, true>), dim3(n_wg), dim3(64 * CE_NW), 0, stream, p, (float2*)ws, n_left);
+      hipLaunchKernelGGL((ce_fwd_reduce_kernel<CH>), dim3((p.B + 3) / 4), dim3(256), 0, stream, p, (const float2*)ws,
+                         n_wg * CE_NW + n_left, lse, row_loss);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (CH > 128) return launch_fwd_t<CH, 1>(p, ws, lse, row_loss, stream);
   else
   switch (pick_tiles_fwd<CH>(p.N)) {
@@ -704,6 +987,29 @@ int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss
 template <int CH>
 int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out, float* d_table,
                hipStream_t stream) {
+  if constexpr (CH == 64) {
+    int n_wg, n_left;
+    const int64_t n_out = (int64_t)p.B * CH;
+    if (split_plan<CH>(p.N, n_wg, n_left) && (n_wg + n_left) * n_out * (int64_t)sizeof(float) <= kSlabLimit) {
+      using C = CeCfg<CH, 6>;
+      constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);
+      constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
+      const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
+      float* slab = (float*)ws;
+      if (d_table) {
+        auto k = ce_bwd_kernel<CH, 6, true, false, true>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr, n_left);
+      } else {
+        auto k = ce_bwd_kernel<CH, 6, false, false, true>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr, n_left);
+      }
+      hipLaunchKernelGGL(ce_bwd_reduce_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, stream, slab, n_wg + n_left,
+                         n_out, d_out);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (CH > 128) return launch_bwd_t<CH, 1>(p, lse, coef, ws, d_out, d_table, stream);
   else
   switch (pick_tiles<CH>(p.N)) {

@@ -10,14 +10,21 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+# the split scheme [round 3] (six item tiles per wave on every CU + leftover tiles swept a quarter per wave, hidden 64,
+# 98,305 .. 102,400 items on 256 CUs): one leftover tile that is itself ragged, a ragged last one of many, all 256, one
+# past the scheme (falls back to seven tiles), and a batch that ends inside a row block
+SPLIT = [(40, 98305, 64), (33, 99990, 64), (48, 102400, 64), (16, 102401, 64), (70, 100000, 64)]
+
+
 @pytest.mark.parametrize("B,N,H", [(512, 100000, 64), (37, 1000, 64), (16, 257, 64), (130, 5003, 128), (1, 64, 64),
-                                   (130, 5003, 256), (2100, 20011, 256)])
+                                   (130, 5003, 256), (2100, 20011, 256)] + SPLIT)
 @pytest.mark.parametrize("scale", [0.02, 1.0])
 def test_fused_ce_matches_materialised_logits(B, N, H, scale):
     g = torch.Generator().manual_seed(B + N)
     out = (scale * torch.randn(B, H, generator=g)).requires_grad_(True)
     table = (scale * torch.randn(N, H, generator=g)).requires_grad_(True)
     target = torch.randint(0, N, (B,), generator=g)
+    target[: B // 4] = N - 1 - torch.arange(B // 4) % min(N, 1500)  # (targets among the last items: the leftover tiles)
     up = torch.randn((), generator=g).item()  # arbitrary upstream factor (the attacked loss uses -1)
     ref = torch.nn.functional.cross_entropy(out.double() @ table.double().t(), target)
     g_out, g_tab = torch.autograd.grad(ref * up, [out, table])
@@ -44,7 +51,7 @@ def test_fused_ce_without_table_gradient():
 
 
 @pytest.mark.parametrize("B,N,H", [(512, 100000, 64), (37, 1000, 64), (16, 257, 64), (130, 5003, 128), (1, 64, 64), (5, 449, 64),
-                                   (70, 3001, 256)])
+                                   (70, 3001, 256)] + SPLIT)
 @pytest.mark.parametrize("scale", [0.02, 1.0, 4.0])
 def test_forward_with_direction_matches_materialised_logits(B, N, H, scale):
     """table_grad=False (acattn_full_sort_ce_fwd_dir): loss and d_out from ONE sweep, for row weights of both signs;
@@ -53,6 +60,7 @@ def test_forward_with_direction_matches_materialised_logits(B, N, H, scale):
     out = (scale * torch.randn(B, H, generator=g)).requires_grad_(True)
     table = (scale * torch.randn(N, H, generator=g)).requires_grad_(True)
     target = torch.randint(0, N, (B,), generator=g)
+    target[: B // 4] = N - 1 - torch.arange(B // 4) % min(N, 1500)
     wrow = torch.randn(B, generator=g)
     ref_rows = torch.nn.functional.cross_entropy(out.double() @ table.double().t(), target, reduction="none")
     g_out, g_tab = torch.autograd.grad((ref_rows * wrow.double()).sum(), [out, table])
