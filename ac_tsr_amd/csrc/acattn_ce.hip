@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(256) ce_dir_reduce_kernel(const acattn_ce_prob
   }
 }
 
-constexpr int64_t kSlabLimit = 96ll << 20;  // bytes of d_out slabs above which the backward uses atomics
+constexpr int64_t kSlabLimit = 512ll << 20;  // bytes of d_out slabs above which the backward uses atomics (96 MB until round 3: configs[3] is 136-162 MB and was paying 34 M float atomics per launch)
 
 static int num_cus() {
   static int n = 0;
@@ -823,17 +823,28 @@ int pick_tiles_fwd(int N) {
   return pick_tiles<CH>(N);
 }
 
-// The split scheme (ce_fwd_kernel): six tiles per wave on every CU + at most one leftover tile per workgroup.  Hidden 64
-// and catalogues whose tile count is 6.x rounds of (CUs x 4 waves): the benchmark's 100,000 items -> 256 workgroups + 106
-// leftover tiles.  ACATTN_CE_SPLIT=0 switches it off (measurement).
+// The split scheme (ce_fwd_kernel): whole rounds of (CUs x 4 waves x T tiles) + at most one leftover tile per workgroup.
+// Hidden 64: T = 6 and one round, for catalogues of 6.x rounds of tiles (the benchmark's 100,000 items -> 256 workgroups +
+// 106 leftover tiles instead of 224 workgroups of seven tiles).  Hidden 128: T = 3 (its maximum) and as many whole rounds
+// as fit (100,000 items -> 512 workgroups + 106 leftover tiles instead of 521 workgroups, i.e. a third round for nine of
+// them).  ACATTN_CE_SPLIT=0 switches it off (measurement).
+template <int CH>
+constexpr int split_tiles() { return CH == 64 ? 6 : 3; }
+
 template <int CH>
 bool split_plan(int N, int& n_wg, int& n_left) {
   static const bool off = getenv("ACATTN_CE_SPLIT") && atoi(getenv("ACATTN_CE_SPLIT")) == 0;
-  if (CH != 64 || off) return false;
+  if ((CH != 64 && CH != 128) || off) return false;
   const int tiles = (N + 15) / 16, per_round = num_cus() * CE_NW;
-  if (tiles / per_round != 6) return false;
-  n_wg = num_cus();
-  n_left = tiles - 6 * per_round;
+  if (CH == 64) {
+    if (tiles / per_round != 6) return false;
+    n_wg = num_cus();
+  } else {
+    const int rounds = tiles / (per_round * 3);
+    if (rounds < 1) return false;
+    n_wg = rounds * num_cus();
+  }
+  n_left = tiles - n_wg * CE_NW * split_tiles<CH>();
   return n_left > 0 && n_left <= n_wg;
 }
 
@@ -897,18 +908,18 @@ int launch_fwd_dir_t(const acattn_ce_problem& p, void* ws, float* lse, float* ro
 
 template <int CH>
 int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, float* dir, hipStream_t stream) {
-  if constexpr (CH == 64) {
+  if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
     const int64_t n_out = (int64_t)p.B * CH;
     if (split_plan<CH>(p.N, n_wg, n_left) && (n_wg + n_left) * n_out * (int64_t)sizeof(float) <= kSlabLimit) {
-      using C = CeCfg<CH, 6>;
+      using C = CeCfg<CH, split_tiles<CH>()>;
       constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);
       constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
       const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
       const int n_slabs = n_wg + n_left;
       float* slab = (float*)ws;
       float2* part = (float2*)(slab + (size_t)n_slabs * n_out);
-      auto k = ce_bwd_kernel<CH, 6, false, true, true>;
+      auto k = ce_bwd_kernel<CH, split_tiles<CH>(), false, true, true>;
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, (const float*)nullptr, (const float*)nullptr,
                          (float*)nullptr, slab, (float*)nullptr, part, n_left);
@@ -932,13 +943,13 @@ int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_
 
 template <int CH>
 int64_t ws_bytes(const acattn_ce_problem& p) {
-  if constexpr (CH == 64) {
+  if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
     if (split_plan<CH>(p.N, n_wg, n_left)) {  // (sized for both forms: the slab limit may send a launch to the other one)
       const int64_t fwd = (int64_t)(n_wg * CE_NW + n_left) * p.B * (int64_t)sizeof(float2);
       const int64_t bwd = (int64_t)(n_wg + n_left) * p.B * CH * (int64_t)sizeof(float);
       const int64_t dirb = bwd + (int64_t)(n_wg + n_left) * p.B * (int64_t)sizeof(float2);
-      const int64_t regular_wg = (p.N + CE_NW * 16 * 7 - 1) / (CE_NW * 16 * 7);
+      const int64_t regular_wg = (p.N + CE_NW * 16 * max_tiles<CH>() - 1) / (CE_NW * 16 * max_tiles<CH>());
       const int64_t regular = std::max(regular_wg * CE_NW * p.B * (int64_t)sizeof(float2),
                                        regular_wg * p.B * (CH * (int64_t)sizeof(float) + (int64_t)sizeof(float2)));
       return std::max(std::max(fwd, regular), dirb <= kSlabLimit ? dirb : bwd <= kSlabLimit ? bwd : 0);
@@ -963,10 +974,10 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
 
 template <int CH>
 int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
-  if constexpr (CH == 64) {
+  if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
     if (split_plan<CH>(p.N, n_wg, n_left)) {
-      hipLaunchKernelGGL((ce_fwd_kernel<CH, 6, true>), dim3(n_wg), dim3(64 * CE_NW), 0, stream, p, (float2*)ws, n_left);
+      hipLaunchKernelGGL((ce_fwd_kernel<CH, split_tiles<CH>(), true>), dim3(n_wg), dim3(64 * CE_NW), 0, stream, p, (float2*)ws, n_left);
       hipLaunchKernelGGL((ce_fwd_reduce_kernel<CH>), dim3((p.B + 3) / 4), dim3(256), 0, stream, p, (const float2*)ws,
                          n_wg * CE_NW + n_left, lse, row_loss);
       return (int)hipGetLastError();
@@ -987,21 +998,21 @@ int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss
 template <int CH>
 int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out, float* d_table,
                hipStream_t stream) {
-  if constexpr (CH == 64) {
+  if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
     const int64_t n_out = (int64_t)p.B * CH;
     if (split_plan<CH>(p.N, n_wg, n_left) && (n_wg + n_left) * n_out * (int64_t)sizeof(float) <= kSlabLimit) {
-      using C = CeCfg<CH, 6>;
+      using C = CeCfg<CH, split_tiles<CH>()>;
       constexpr int TS = C::ITEMS + 16 + ((C::ITEMS / 16 + 1) % 2 ? 0 : 16);
       constexpr int XS = (16 * TS > 16 * C::ES) ? 16 * TS : 16 * C::ES;
       const size_t lds = (size_t)(CE_NW * C::ITEMS * C::ES + 16 * C::ES + CE_NW * XS) * sizeof(float);
       float* slab = (float*)ws;
       if (d_table) {
-        auto k = ce_bwd_kernel<CH, 6, true, false, true>;
+        auto k = ce_bwd_kernel<CH, split_tiles<CH>(), true, false, true>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr, n_left);
       } else {
-        auto k = ce_bwd_kernel<CH, 6, false, false, true>;
+        auto k = ce_bwd_kernel<CH, split_tiles<CH>(), false, false, true>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * CE_NW), lds, stream, p, lse, coef, d_out, slab, d_table, (float2*)nullptr, n_left);
       }
