@@ -677,6 +677,9 @@ __global__ void __launch_bounds__(64 * NWV, ACATTN_PROJ_WAVES) proj_staged_fwd_k
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       if (!W.ok[nb]) continue;
+#ifdef ACATTN_PROJ_NOSTORE
+      if (a[nb][0] != 12345.678f) continue;
+#endif
       float* dst = out + (size_t)W.row[nb] * ld + j0;
       if (j0 + 3 < n_out) {
         *(f4u*)dst = a[nb];
@@ -690,7 +693,11 @@ __global__ void __launch_bounds__(64 * NWV, ACATTN_PROJ_WAVES) proj_staged_fwd_k
   auto masked_store_rows = [&](float* out, const f4 (&v)[NB][DT]) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
+#ifdef ACATTN_PROJ_NOSTORE
+      if (W.ok[nb] && v[nb][0][0] == 12345.678f)
+#else
       if (W.ok[nb])
+#endif
 #pragma unroll
         for (int t = 0; t < DT; ++t) *(f4*)(out + (size_t)W.row[nb] * H + 16 * t + 4 * g) = v[nb][t];
   };
