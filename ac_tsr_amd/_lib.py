@@ -55,7 +55,7 @@ class BwdIO(C.Structure):
         ("dq", _f), ("dk", _f), ("dv", _f), ("dqa", _f), ("dka", _f), ("dgate_logits", _f),
         ("dw_order_part", _f), ("dw_dist_part", _f), ("dsmall_part", _f), ("part_stride", C.c_int32),
         ("active_qblocks", _f), ("attack_only", C.c_int32), ("workspace", _f), ("read_rows", _f),
-        ("n_read_rows", C.c_int32),
+        ("n_read_rows", C.c_int32), ("d_penalty_part", _f),
     ]
 
 
@@ -165,6 +165,10 @@ SYMBOLS = {
                                                        C.c_void_p]),
     "acattn_attacked_loss_finish": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_int64, C.c_float, _f, _f, C.c_int32,
                                               C.c_void_p]),
+    "acattn_mask_penalty_rows": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, _f, C.c_void_p]),
+    "acattn_attacked_loss_finish_rows": (C.c_int, [_f, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f, _f, C.c_int32,
+                                                  C.c_void_p]),
+    "acattn_mask_penalty_drows": (C.c_int, [_f, _f, C.c_float, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "acattn_mask_penalty_bwd_scaled": (C.c_int, [_f, _f, _f, C.c_float, C.c_int64, _f, C.c_void_p]),
     "acattn_mask_penalty_bwd": (C.c_int, [_f, _f, _f, C.c_int64, _f, C.c_void_p]),
     "acattn_linear_wgrad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),

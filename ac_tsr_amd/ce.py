@@ -228,6 +228,69 @@ class _AttackedLoss(torch.autograd.Function):
         return (d_out, d_table, None, None, None, *d_masks)
 
 
+class _AttackedLossRows(torch.autograd.Function):
+    """_AttackedLoss with the mask penalty taken from the attention nodes' row sums (ops.PENALTY_ROWS: `pen_l` =
+    acattn_mask_penalty_rows(M_l), [B, nh, ceil(L/16)], || 1 - M_l ||^2 = sum pen_l) instead of from the masks: no pass
+    over M in the forward, and the backward returns d pen_l = d_loss * weight / n / (2 || 1 - M_l ||) -- a vector of a few
+    thousand equal entries per layer -- instead of a dense d M_l; the attention backward kernels form
+    d M = 2 d_pen (M - 1) from the tile they rebuild (acattn_bwd_io.d_penalty_part)."""
+
+    @staticmethod
+    def forward(ctx, out, table, target, weight, state, *pens):
+        ctx.state = state
+        lib = _lib.load()
+        B = out.shape[0]
+        p = _problem(out, table, target)
+        nbytes = lib.acattn_full_sort_ce_workspace_bytes(C.byref(p))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
+        lse = torch.empty(B, device=out.device, dtype=torch.float32)
+        row_loss = torch.empty_like(lse)
+        direction = torch.empty_like(out)
+        rc = lib.acattn_full_sort_ce_fwd_dir(C.byref(p), _ptr(ws), _ptr(lse), _ptr(row_loss), _ptr(direction), _stream())
+        if rc == -100:  # too many rows for the per-workgroup slabs: plain forward, regular backward sweep
+            direction = None
+            _lib.check(lib.acattn_full_sort_ce_fwd(C.byref(p), _ptr(ws), _ptr(lse), _ptr(row_loss), _stream()), "full_sort_ce_fwd")
+        else:
+            _lib.check(rc, "full_sort_ce_fwd_dir")
+        pens = tuple(t.contiguous() for t in pens)
+        ptrs = (C.c_void_p * len(pens))(*(t.data_ptr() for t in pens))
+        res = torch.empty(2 + len(pens), device=out.device, dtype=torch.float32)
+        _lib.check(lib.acattn_attacked_loss_finish_rows(_ptr(row_loss), B, ptrs, len(pens), pens[0].numel(), weight, _ptr(res),
+                                                        _ptr(direction), 0 if direction is None else direction.numel(),
+                                                        _stream()), "attacked_loss_finish_rows")
+        ctx.has_dir = direction is not None
+        ctx.save_for_backward(out, table, target, lse, direction if direction is not None else lse, res)
+        ctx.weight, ctx.ws_bytes, ctx.pen_shapes = weight, nbytes, [t.shape for t in pens]
+        return res[0]
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        out, table, target, lse, direction, res = ctx.saved_tensors
+        lib = _lib.load()
+        d_loss = d_loss.contiguous()
+        d_table = None
+        want_table = ctx.needs_input_grad[1] and not ctx.state.attack_pass_only
+        if want_table or not ctx.has_dir:
+            p = _problem(out, table, target)
+            p.coef_is_scalar, p.coef_scale = 1, -1.0 / out.shape[0]
+            ws = torch.empty(ctx.ws_bytes, dtype=torch.uint8, device=out.device)
+            d_out, d_table = torch.empty_like(out), (torch.empty_like(table) if want_table else None)
+            _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_loss), _ptr(ws), _ptr(d_out), _ptr(d_table),
+                                                   _stream()), "full_sort_ce_bwd")
+        else:
+            d_out = direction * d_loss  # direction already carries -1/B
+        n = len(ctx.pen_shapes)
+        count = 1
+        for d in ctx.pen_shapes[0]:
+            count *= d
+        d_flat = torch.empty(n, count, device=out.device, dtype=torch.float32)  # every layer's vector in one launch
+        dp = (C.c_void_p * n)(*(d_flat[l].data_ptr() for l in range(n)))
+        _lib.check(lib.acattn_mask_penalty_drows(_ptr(res[2:]), _ptr(d_loss), ctx.weight / n, count, dp, n, _stream()),
+                   "mask_penalty_drows")
+        d_pens = [d_flat[l].view(ctx.pen_shapes[l]) if ctx.needs_input_grad[5 + l] else None for l in range(n)]
+        return (d_out, d_table, None, None, None, *d_pens)
+
+
 def attacked_loss(output: torch.Tensor, table: torch.Tensor, target: torch.Tensor, masks, weight: float,
                   state=_DEFAULT_STATE):
     """-CE(output @ table^T, target) + weight * mean_l ||1 - M_l||_2 (acsasrec.py:129-137) as one autograd node, or None
@@ -236,6 +299,11 @@ def attacked_loss(output: torch.Tensor, table: torch.Tensor, target: torch.Tenso
     if not masks or any(m.numel() != masks[0].numel() or m.dtype != torch.float32 or not m.is_cuda for m in masks):
         return None
     _need_cuda("target", target, torch.int64)
+    from . import ops
+    pens = [getattr(m, "_acattn_pen", None) for m in masks]
+    if (ops.PENALTY_ROWS and len(masks) <= _lib.MAX_MASKS and all(t is not None and t.is_cuda for t in pens)
+            and all(t.shape == pens[0].shape for t in pens)):
+        return _AttackedLossRows.apply(output.contiguous(), table, target, float(weight), state, *pens)
     return _AttackedLoss.apply(output.contiguous(), table, target, float(weight), state, *masks)
 
 

@@ -361,6 +361,38 @@ int acattn_attacked_loss_finish(const float* row_loss, int32_t B, const float* p
   return rc;
 }
 
+int acattn_mask_penalty_rows(const float* m, int32_t B, int32_t n_heads, int32_t L, float* pen, void* stream) {
+  if (!m || !pen) return fail("m and pen must be non-NULL");
+  if (B < 1 || n_heads < 1 || L < 1) return fail("B, n_heads and L must be positive");
+  const int rc = acattn_launch_penalty_rows(m, B, n_heads, L, pen, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_attacked_loss_finish_rows(const float* row_loss, int32_t B, const float* const* pen, int32_t n_masks, int32_t count,
+                                     float weight, float* out, float* scale_buf, int32_t n_scale, void* stream) {
+  if (!row_loss || !pen || !out) return fail("row_loss, pen and out must be non-NULL");
+  if (B < 1 || count < 1 || n_masks < 1 || n_masks > ACATTN_MAX_MASKS) return fail("B, count positive, 1 <= n_masks <= ACATTN_MAX_MASKS");
+  for (int l = 0; l < n_masks; ++l)
+    if (!pen[l]) return fail("every pen vector must be non-NULL");
+  if (n_scale < 0 || (n_scale > 0 && !scale_buf)) return fail("scale_buf must be given with n_scale > 0");
+  const int rc = acattn_launch_attacked_loss_finish_rows(row_loss, B, pen, n_masks, count, weight, out, scale_buf, n_scale,
+                                                         (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
+int acattn_mask_penalty_drows(const float* norms, const float* d_loss, float scale, int32_t count, float* const* d_pen,
+                              int32_t n_masks, void* stream) {
+  if (!norms || !d_loss || !d_pen) return fail("norms, d_loss and d_pen must be non-NULL");
+  if (count < 1 || n_masks < 1 || n_masks > ACATTN_MAX_MASKS) return fail("count positive, 1 <= n_masks <= ACATTN_MAX_MASKS");
+  for (int l = 0; l < n_masks; ++l)
+    if (!d_pen[l]) return fail("every d_pen vector must be non-NULL");
+  const int rc = acattn_launch_penalty_drows(norms, d_loss, scale, count, d_pen, n_masks, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int acattn_mask_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n, float* d_m,
                                    void* stream) {
   if (!m || !norm || !d_loss || !d_m) return fail("m, norm, d_loss and d_m must be non-NULL");

@@ -40,7 +40,7 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
     // linear in its cotangents: the mask cotangent alone (no context cotangent anywhere: every query block takes the
     // mask-only path of the row-resident kernel, which then owes dqa and dka only) + the read row's chain added on top.
     static const bool split = getenv("ACATTN_ONEROW_SPLIT") ? atoi(getenv("ACATTN_ONEROW_SPLIT")) != 0 : true;
-    if (split && io.d_attack_mask && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.attack_only && p.L <= 64) {
+    if (split && (io.d_attack_mask || io.d_penalty_part) && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.attack_only && p.L <= 64) {
       acattn_bwd_io mask_io = io;
       mask_io.d_ctx_attacked = mask_io.d_ctx_calibrated = nullptr;
       mask_io.n_read_rows = 0;   // no block holds a read position
@@ -49,6 +49,7 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
       if (rc_mask == 0) {
         acattn_bwd_io row_io = io;
         row_io.d_attack_mask = nullptr;
+        row_io.d_penalty_part = nullptr;
         const int rc_row = acattn_launch_bwd_onerow(p, row_io, true, stream);
         if (rc_row != -100) return rc_row;
         return -1;  // the mask launch ran: the read row's chain must not be dropped silently

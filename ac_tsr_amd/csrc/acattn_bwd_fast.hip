@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
   const bool has_drop = P.p_drop > 0.f;
   const float keep_scale = has_drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
   const uint32_t prow = ((uint32_t)bh * L + (row_ok ? i : 0)) * (uint32_t)L;
+  const float dpen2 = IO.d_penalty_part ? 2.0f * IO.d_penalty_part[(size_t)bh * nT + qb] : 0.f;  // (uniform per wave)
   const uint32_t rng_row = (uint32_t)(bh * L + i);
   const float okf = row_ok ? 1.0f : 0.0f;
 
@@ -543,6 +544,8 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
         sa[r] = ((keepA >> (4 * t + r)) & 1u) ? keep_scale : 0.f;
         sm[r] = ((keepM >> (4 * t + r)) & 1u) ? keep_scale : 0.f;
       }
+      // the mask penalty's cotangent from the rebuilt tile (acattn_bwd_io.d_penalty_part): d M = 2 d_pen (M - 1), M = Mt . keep
+      if (IO.d_penalty_part) dMa[t] += (tM[t] * sm - 1.0f) * dpen2;
       dMa[t] *= sm;
       r2 += hsum(tM[t] * dMa[t]);
       if constexpr (!MASK_ONLY) {

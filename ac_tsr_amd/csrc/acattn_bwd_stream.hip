@@ -423,6 +423,8 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
   const bool order_select = !causal || __ballot(R.dead) != 0ull;
   const float* grow = P.gate_logits + (rowbase + (R.row_ok ? R.i : 0)) * L;
   const float* dmrow = IO.d_attack_mask ? IO.d_attack_mask + prow : nullptr;
+  // the mask penalty's cotangent formed from the rebuilt tile (acattn_bwd_io.d_penalty_part): d M += 2 d_pen (M - 1)
+  const float dpen2 = IO.d_penalty_part ? 2.0f * IO.d_penalty_part[(size_t)bh * nT + qb] : 0.f;
 
   auto build = [&](int t, Tile& T) {
     f4 k4[DT], ka4[DT], v4[DT];
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
   for (int t = 0; t < nt; ++t) {
     Tile T;
     build(t, T);
-    const f4 dMout = dmrow ? load_seg(dmrow, 16 * t + 4 * g, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 dMout = (dmrow ? load_seg(dmrow, 16 * t + 4 * g, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f}) + (T.M - 1.0f) * dpen2;
     const f4 apd = T.Ap * T.dAp;
     const f4 alpha = T.Aw * T.dAw, beta = T.Aw;
     const f4 gam = T.Ac * (1.0f - T.gt);
@@ -482,7 +484,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     Tile T;
     build(t, T);
     const int j0 = 16 * t + 4 * g;
-    const f4 dMout = dmrow ? load_seg(dmrow, j0, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 dMout = (dmrow ? load_seg(dmrow, j0, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f}) + (T.M - 1.0f) * dpen2;
     f4 dS, dSa, dgl, d_o, d_d;
     float dsc;
     tile_backward(T, K, da, dc, r1, sP, sM, dMout, R.i, j0, dS, dSa, dgl, d_o, d_d, dsc);
@@ -606,11 +608,12 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     const uint32_t prow = prow_base + (uint32_t)(R.row_ok ? R.i : 0) * (uint32_t)L;
     const int j0 = 16 * t + 4 * g;
     const f4 gl = load_seg(P.gate_logits + (rowbase + (R.row_ok ? R.i : 0)) * L, j0, L, R.row_ok);
-    const f4 dMout = IO.d_attack_mask ? load_seg(IO.d_attack_mask + prow, j0, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
+    f4 dMout = IO.d_attack_mask ? load_seg(IO.d_attack_mask + prow, j0, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
     uint32_t eb4, ab4;
     tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
     Tile T;
     tile_forward<DH>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+    if (IO.d_penalty_part) dMout += (T.M - 1.0f) * (2.0f * IO.d_penalty_part[(size_t)bh * nT + qb]);
     f4 dS, dSa, dgl, d_o, d_d;
     float dsc;
     tile_backward(T, K, w0[0], w0[1], w0[2], w0[3], sM, dMout, R.i, j0, dS, dSa, dgl, d_o, d_d, dsc);
@@ -981,7 +984,7 @@ int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p) { return (int64_t)p.
 // `accumulate`: see the kernel (the caller has run the mask path; io.d_attack_mask must then be NULL here).
 int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream) {
   static const bool enabled = getenv("ACATTN_ONEROW") ? atoi(getenv("ACATTN_ONEROW")) != 0 : true;
-  const bool ok = enabled && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.d_attack_mask && !io.attack_only &&
+  const bool ok = enabled && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.d_attack_mask && !io.d_penalty_part && !io.attack_only &&
                   p.L <= 208 && (int64_t)p.B * p.n_heads * p.L * p.L < (1LL << 30) && (int64_t)p.B * p.L * p.H < (1LL << 30) &&
                   p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order && p.w_dist &&
                   p.adversarial && p.combine_option == ACATTN_COMBINE_GATE && p.two_level;

@@ -283,7 +283,7 @@ __device__ __forceinline__ bool qblock_has_ctx(const acattn_bwd_io& IO, int b, i
 }
 
 __device__ __forceinline__ bool qblock_active(const acattn_bwd_io& IO, int b, int qb) {
-  if (IO.d_attack_mask) return true;  // the mask cotangent reaches every row
+  if (IO.d_attack_mask || IO.d_penalty_part) return true;  // the mask cotangent reaches every row
   if (IO.active_qblocks) return (IO.active_qblocks[b] >> qb) & 1u;
   if (IO.read_rows) {
     for (int r = 0; r < IO.n_read_rows; ++r)
@@ -346,6 +346,11 @@ int acattn_launch_embed_bwd(const acattn_embed_problem& p, const float* dy, cons
                             float* d_table, float* d_pos_part, float* dgb_part, hipStream_t stream);
 int acattn_launch_penalty_fwd(const float* m, int64_t n, float* ws, float* norm, hipStream_t stream);
 int acattn_launch_penalty_partial(const float* m, int64_t n, float* part, hipStream_t stream);
+int acattn_launch_penalty_rows(const float* m, int B, int nh, int L, float* pen, hipStream_t stream);
+int acattn_launch_attacked_loss_finish_rows(const float* row_loss, int B, const float* const* pen, int n_masks, int count,
+                                            float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream);
+int acattn_launch_penalty_drows(const float* norms, const float* d_loss, float scale, int count, float* const* d_pen,
+                                int n_masks, hipStream_t stream);
 int acattn_launch_attacked_loss_finish(const float* row_loss, int B, const float* part, int n_masks, int64_t mask_numel,
                                        float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream);
 int acattn_launch_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n,

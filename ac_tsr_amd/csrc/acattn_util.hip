@@ -265,6 +265,108 @@ int acattn_launch_penalty_bwd_scaled_multi(const float* const* m, const float* n
   return (int)hipGetLastError();
 }
 
+// pen[bh * nT + qb] = sum over rows [16 qb, 16 qb + 16) x L keys of (1 - M)^2: the block is 16 L contiguous floats
+__global__ void __launch_bounds__(64) penalty_rows_kernel(const float* __restrict__ m, const int L, const int nT,
+                                                          float* __restrict__ pen) {
+  const int blk = blockIdx.x, bh = blk / nT, qb = blk - bh * nT;
+  const int rows = min(16, L - 16 * qb), n = rows * L;
+  const float* p = m + ((size_t)bh * L + 16 * qb) * L;
+  float acc = 0.f;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  if (aligned) {
+    for (int i = 4 * threadIdx.x; i + 3 < n; i += 256) {
+      const f4 v = 1.0f - *(const f4*)(p + i);
+      acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    for (int i = (n & ~3) + threadIdx.x; i < n; i += 64) acc += (1.0f - p[i]) * (1.0f - p[i]);
+  } else {
+    for (int i = threadIdx.x; i < n; i += 64) acc += (1.0f - p[i]) * (1.0f - p[i]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (threadIdx.x == 0) pen[blk] = acc;
+}
+
+struct PenaltyRows {
+  const float* pen[ACATTN_MAX_MASKS];
+  float* d_pen[ACATTN_MAX_MASKS];
+};
+
+// attacked_loss_finish_kernel with one pen vector per mask (see there)
+__global__ void __launch_bounds__(256) attacked_loss_finish_rows_kernel(const float* __restrict__ row_loss, const int B,
+                                                                        const PenaltyRows R, const int n_masks, const int count,
+                                                                        const float weight, float* __restrict__ out,
+                                                                        float* __restrict__ scale_buf, const int n_scale) {
+  const float k = -1.0f / (float)B;
+  if (blockIdx.x > 0) {
+    for (int i = (blockIdx.x - 1) * 256 + threadIdx.x; i < n_scale / 4; i += (gridDim.x - 1) * 256)
+      *(f4*)(scale_buf + 4 * i) = *(const f4*)(scale_buf + 4 * i) * k;
+    if (blockIdx.x == 1 && threadIdx.x < (n_scale & 3)) scale_buf[(n_scale & ~3) + threadIdx.x] *= k;
+    return;
+  }
+  __shared__ float red[256];
+  auto block_sum = [&](float v) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) acc += row_loss[i];
+  const float ce = block_sum(acc) / (float)B;
+  float pen = 0.f;
+  for (int l = 0; l < n_masks; ++l) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) a += R.pen[l][i];
+    const float nv = sqrtf(block_sum(a));
+    if (threadIdx.x == 0) out[2 + l] = nv;
+    pen += nv;
+  }
+  if (threadIdx.x == 0) {
+    out[0] = weight * (pen / (float)n_masks) - ce;
+    out[1] = ce;
+  }
+}
+
+// d_pen[l][:] = d_loss * scale / (2 norm_l)
+__global__ void __launch_bounds__(256) penalty_drows_kernel(const PenaltyRows R, const float* __restrict__ norms,
+                                                            const float* __restrict__ d_loss, const float scale, const int count) {
+  const float nv = norms[blockIdx.y];
+  const float k = nv > 0.f ? d_loss[0] * scale / (2.0f * nv) : 0.f;
+  float* d = R.d_pen[blockIdx.y];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) d[i] = k;
+}
+
+int acattn_launch_penalty_rows(const float* m, int B, int nh, int L, float* pen, hipStream_t stream) {
+  const int nT = (L + 15) / 16;
+  hipLaunchKernelGGL(penalty_rows_kernel, dim3(B * nh * nT), dim3(64), 0, stream, m, L, nT, pen);
+  return (int)hipGetLastError();
+}
+
+int acattn_launch_attacked_loss_finish_rows(const float* row_loss, int B, const float* const* pen, int n_masks, int count,
+                                            float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream) {
+  PenaltyRows R{};
+  for (int l = 0; l < n_masks; ++l) R.pen[l] = pen[l];
+  const int scale_wgs = n_scale > 0 ? std::min((n_scale / 4 + 255) / 256 + 1, 64) : 0;
+  hipLaunchKernelGGL(attacked_loss_finish_rows_kernel, dim3(1 + scale_wgs), dim3(256), 0, stream, row_loss, B, R, n_masks,
+                     count, weight, out, scale_buf, n_scale);
+  return (int)hipGetLastError();
+}
+
+int acattn_launch_penalty_drows(const float* norms, const float* d_loss, float scale, int count, float* const* d_pen,
+                                int n_masks, hipStream_t stream) {
+  PenaltyRows R{};
+  for (int l = 0; l < n_masks; ++l) R.d_pen[l] = d_pen[l];
+  hipLaunchKernelGGL(penalty_drows_kernel, dim3(std::max(1, std::min((count + 255) / 256, 64)), n_masks), dim3(256), 0, stream,
+                     R, norms, d_loss, scale, count);
+  return (int)hipGetLastError();
+}
+
 int acattn_launch_attacked_loss_finish(const float* row_loss, int B, const float* part, int n_masks, int64_t mask_numel,
                                        float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream) {
   const int scale_wgs = n_scale > 0 ? std::min((n_scale / 4 + 255) / 256 + 1, 64) : 0;

@@ -36,7 +36,7 @@ _LIB.define(
     "bool causal, Tensor w_order, Tensor b_order, Tensor w_dist, Tensor b_dist, Tensor scalar, int n_heads, "
     "float p_drop, int seed, Tensor? seed_tensor, bool gate_is_prob, Tensor attack_mask, Tensor row_stats, "
     "Tensor? d_ctx_attacked, Tensor? d_ctx_calibrated, Tensor? d_attack_mask, Tensor? read_rows, Tensor? active_qblocks, "
-    "bool attack_only) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
+    "bool attack_only, Tensor? d_penalty_part=None) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -107,9 +107,9 @@ def _fwd_meta(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
 
 def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
               seed_tensor, gate_is_prob, attack_mask, row_stats, d_ctx_attacked, d_ctx_calibrated, d_attack_mask, read_rows,
-              active_qblocks, attack_only):
+              active_qblocks, attack_only, d_penalty_part=None):
     _check_inputs(q, k, v, qa, ka, gate, key_valid, attack_mask, row_stats, d_ctx_attacked, d_ctx_calibrated, d_attack_mask,
-                  read_rows, active_qblocks)
+                  read_rows, active_qblocks, d_penalty_part)
     lib = _lib.load()
     B, L, H = q.shape
     dh = H // n_heads
@@ -135,13 +135,14 @@ def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
     if read_rows is not None:
         io.read_rows, io.n_read_rows = _ptr(read_rows), read_rows.shape[1]
     io.attack_only = int(attack_only)
+    io.d_penalty_part = _ptr(d_penalty_part)  # [B, n_heads, ceil(L/16)]: include/acattn.h
     _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
     return dq, dk, dv, dqa, dka, dgate_part, part
 
 
 def _bwd_meta(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
               seed_tensor, gate_is_prob, attack_mask, row_stats, d_ctx_attacked, d_ctx_calibrated, d_attack_mask, read_rows,
-              active_qblocks, attack_only):
+              active_qblocks, attack_only, d_penalty_part=None):
     B, L, H = q.shape
     dh = H // n_heads
     e = lambda: torch.empty_like(q)

@@ -44,6 +44,11 @@ def _penalty(attack_mask, mode="local"):
     if mode == "global":
         from .parallel import global_mask_penalty
         return global_mask_penalty(attack_mask)
+    pen = getattr(attack_mask, "_acattn_pen", None)  # the attention node's row sums of (1 - M)^2 (ops.PENALTY_ROWS)
+    if pen is not None:
+        from . import ops
+        if ops.PENALTY_ROWS:
+            return torch.sqrt(pen.sum())  # gradient: a [B, nh, ceil(L/16)] cotangent into the attention backward, no dense d M
     if attack_mask.is_cuda and attack_mask.dtype == torch.float32:
         return mask_penalty(attack_mask)
     return torch.norm(1 - attack_mask, p=2)

@@ -174,6 +174,12 @@ def _fill_problem(q, k, v, qa, ka, gate_logits, mask, w_order, b_order, w_dist, 
 # probability dumps) through the dispatcher operators of dispatch.py (torch.ops.acattn.*); everything else, and every call
 # when this is False, goes to the C ABI directly.  Same kernels either way.
 USE_DISPATCHER = True
+# The attention node also returns, as its last output, acattn_mask_penalty_rows of its attack mask: sum (1 - M)^2 per
+# (sequence, head, query block).  A loss that takes the mask penalty || 1 - M ||_2 (acsasrec.py:131-137) from these sums
+# sends back a [B, nh, ceil(L/16)] cotangent instead of a dense [B, nh, L, L] one, and the backward kernels form
+# d M = 2 d_pen (M - 1) from the tile they rebuild (acattn_bwd_io.d_penalty_part).  The mask tensor carries the sums as
+# `M._acattn_pen` (ce.attacked_loss looks for it); False = the node returns None there.
+PENALTY_ROWS = True
 
 
 def _dispatcher_form(cfg, mask, rnd, want_probs, w_order, w_dist) -> bool:
@@ -226,7 +232,7 @@ class _CalibratedAttention(torch.autograd.Function):
                 ctx_att = M = stats = None
             ctx.cfg, ctx.p_drop, ctx.rnd, ctx.seed, ctx.mask, ctx.seed_tensor = cfg, p_drop, rnd, seed, mask, seed_tensor
             ctx.save_for_backward(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats)
-            return (ctx_att, ctx_cal, M, None, None, None, None)
+            return (ctx_att, ctx_cal, M, None, None, None, None, _CalibratedAttention._penalty_rows(ctx, lib, M, cfg))
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
                              p_drop, rnd, seed, keep, seed_tensor, gate_is_prob, affine)
         out = FwdOut()
@@ -249,7 +255,16 @@ class _CalibratedAttention(torch.autograd.Function):
         outs = [ctx_att, ctx_cal, M] + [probs.get(n) for n in
                                         ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")]
         ctx.mark_non_differentiable(*[t for t in outs[3:] if t is not None])
-        return tuple(outs)
+        return tuple(outs) + (_CalibratedAttention._penalty_rows(ctx, lib, M, cfg),)
+
+    @staticmethod
+    def _penalty_rows(ctx, lib, M, cfg):
+        if not (PENALTY_ROWS and cfg.adversarial and M is not None and any(ctx.needs_input_grad[:12])):
+            return None
+        B, nh, L, _ = M.shape
+        pen = torch.empty(B, nh, (L + 15) // 16, device=M.device, dtype=torch.float32)
+        _lib.check(lib.acattn_mask_penalty_rows(_ptr(M), B, nh, L, _ptr(pen), _stream()), "mask_penalty_rows")
+        return pen
 
     @staticmethod
     def backward(ctx, d_att, d_cal, d_M, *_unused):
@@ -268,12 +283,13 @@ class _CalibratedAttention(torch.autograd.Function):
         d_att = None if d_att is None else d_att.contiguous()
         d_cal = None if d_cal is None else d_cal.contiguous()
         d_M = None if d_M is None else d_M.contiguous()
+        d_pen = _unused[4].contiguous() if len(_unused) > 4 and _unused[4] is not None else None
         if ctx.via_dispatcher:
             attack_only = ctx.state.attack_pass_only and not ctx.attack_upstream
             dq, dk, dv, dqa, dka, dgate_part, part = torch.ops.acattn.calibrated_attention_bwd(
                 q, k, v, qa, ka, gate_logits, ctx.mask.key_valid, bool(ctx.mask.causal), wo.contiguous(), b_order,
                 wd.contiguous(), b_dist, scalar, nh, float(ctx.p_drop), int(ctx.seed) & 0x7FFFFFFFFFFFFFFF, ctx.seed_tensor,
-                bool(ctx.gate_is_prob), M, stats, d_att, d_cal, d_M, ctx.read_rows, ctx.active_qblocks, bool(attack_only))
+                bool(ctx.gate_is_prob), M, stats, d_att, d_cal, d_M, ctx.read_rows, ctx.active_qblocks, bool(attack_only), d_pen)
             return _CalibratedAttention._finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh,
                                                          w_order, b_order, w_dist, b_dist, scalar, rich_ratio)
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, ctx.mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
@@ -281,6 +297,7 @@ class _CalibratedAttention(torch.autograd.Function):
         io = BwdIO()
         io.attack_mask, io.row_stats = _ptr(M), _ptr(stats)
         io.d_ctx_attacked, io.d_ctx_calibrated, io.d_attack_mask = _ptr(d_att), _ptr(d_cal), _ptr(d_M)
+        io.d_penalty_part = _ptr(d_pen)
         dq, dk, dv, dqa, dka = (torch.empty_like(q) for _ in range(5))
         io.dq, io.dk, io.dv, io.dqa, io.dka = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqa), _ptr(dka)
         dgate = dgate_part = None
@@ -371,7 +388,9 @@ def calibrated_attention(q, k, v, qa, ka, gate_logits, mask, cfg: AttentionConfi
                                       rich_ratio, mask, cfg, p_drop, rnd, seed or 0, want_probs, seed_tensor, read_rows,
                                       attack_upstream, state, gate_is_prob, affine)
     names = ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")
-    probs = {n: t for n, t in zip(names, outs[3:]) if t is not None}
+    probs = {n: t for n, t in zip(names, outs[3:7]) if t is not None}
+    if outs[7] is not None:
+        outs[2]._acattn_pen = outs[7]  # see PENALTY_ROWS
     return outs[0], outs[1], outs[2], probs
 
 

@@ -155,6 +155,10 @@ typedef struct acattn_bwd_io {
                            (the reference's gather raises an index error otherwise); the kernels clamp a position
                            outside that range into it rather than touch another sequence's memory. */
   int32_t n_read_rows;
+  const float* d_penalty_part; /* ABI 26, optional: [B, nh, ceil(L/16)] cotangent of acattn_mask_penalty_rows' sums.  The
+                           kernels then add d M = 2 * d_penalty_part[b, head, query block] * (M - 1) to the mask cotangent
+                           from the M tile they rebuild -- the mask penalty's gradient (acsasrec.py:131-137) without a
+                           dense [B,nh,L,L] cotangent.  Like d_attack_mask it keeps every query block active. */
 } acattn_bwd_io;
 
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
@@ -275,6 +279,18 @@ int acattn_attacked_loss_finish(const float* row_loss, int32_t B, const float* p
                                 float weight, float* out, float* scale_buf, int32_t n_scale, void* stream);
 int acattn_mask_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n, float* d_m,
                                    void* stream);
+/* The penalty through the attention node instead of through M [round 3]:
+ * acattn_mask_penalty_rows: pen[b, head, qb] = sum over the rows of query block qb (16 rows) and all L keys of (1 - M)^2,
+ *   M [B,nh,L,L] -> pen [B, nh, ceil(L/16)].  The sum of pen is || 1 - M ||_2 ^ 2.
+ * acattn_attacked_loss_finish_rows: acattn_attacked_loss_finish with one pen vector (count floats) per mask in place of the
+ *   partial-sum workspace.
+ * acattn_mask_penalty_drows: d_pen[l][:] = d_loss * scale / (2 * norm_l) for every mask l (count floats each), i.e. the
+ *   cotangent of pen under loss = ... + scale * sum_l sqrt(sum pen_l): feed it to acattn_bwd_io.d_penalty_part. */
+int acattn_mask_penalty_rows(const float* m, int32_t B, int32_t n_heads, int32_t L, float* pen, void* stream);
+int acattn_attacked_loss_finish_rows(const float* row_loss, int32_t B, const float* const* pen, int32_t n_masks, int32_t count,
+                                     float weight, float* out, float* scale_buf, int32_t n_scale, void* stream);
+int acattn_mask_penalty_drows(const float* norms, const float* d_loss, float scale, int32_t count, float* const* d_pen,
+                              int32_t n_masks, void* stream);
 /* The same two for all masks of a model (one per layer, each of n elements, at most ACATTN_MAX_MASKS) in ONE launch each:
  * part [n_masks, ACATTN_PENALTY_WS_FLOATS]; norms [n_masks] (the out + 2 of acattn_attacked_loss_finish). */
 #define ACATTN_MAX_MASKS 8

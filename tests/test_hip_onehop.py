@@ -323,3 +323,39 @@ def test_one_level_backward_beyond_64_matches_oracle_autograd(B, L, H, nh, causa
         if err > 2e-3 * scale + 1e-7:
             bad.append((k, err, scale))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,L,H,nh,causal,read_row", [(512, 50, 64, 2, True, False), (512, 50, 64, 2, True, True),
+                                                      (8, 200, 128, 4, True, False), (6, 200, 64, 2, False, True),
+                                                      (4, 130, 256, 2, True, False)],
+                         ids=["bench_shape", "bench_shape_read_row", "cfg4_shape", "L200_bidirectional_read_row", "dh128"])
+def test_penalty_row_sums_carry_the_mask_penalty_gradient(B, L, H, nh, causal, read_row):
+    """ops.PENALTY_ROWS: the attention node's last output pen = acattn_mask_penalty_rows(M) (sum (1 - M)^2 per sequence,
+    head and query block).  || 1 - M ||_2 (acsasrec.py:131-137) taken from pen gives the loss value of torch.norm(1 - M)
+    and -- through acattn_bwd_io.d_penalty_part, d M = 2 d_pen (M - 1) formed inside the backward kernels -- the gradients
+    the dense mask cotangent gives; with a context cotangent at one read row per sequence as well (the trainer's attacked
+    pass through the last layer: mask-only blocks + the one-row chain at L <= 64)."""
+    t, kv, lens, g = _problem(B, L, H, nh, seed=L + H, causal=causal)
+    names = ["q", "k", "v", "qa", "ka", "gl", "w_order", "b_order", "w_dist", "b_dist", "scalar"]
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
+    mask = A.StructuredMask(kv.to(DEV), causal=causal)
+    rows = (lens - 1).view(-1, 1)
+    row_cot = torch.randn(B, 1, H, generator=g).to(DEV)
+    idx = rows.unsqueeze(-1).expand(-1, -1, H).to(DEV)
+    res = []
+    for via_rows in (False, True):
+        dev = {k: t[k].to(DEV).requires_grad_(True) for k in names}
+        ctx_a, ctx_c, M, _ = A.calibrated_attention(dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev["gl"], mask, cfg,
+                                                    p_drop=0.5, seed=4242, read_rows=rows.to(DEV) if read_row else None,
+                                                    **{k: dev[k] for k in names[6:]})
+        pen = M._acattn_pen
+        assert pen.shape == (B, nh, (L + 15) // 16)
+        norm = torch.sqrt(pen.sum()) if via_rows else torch.norm(1 - M, p=2)
+        loss = 0.03 * norm
+        if read_row:
+            loss = loss + (ctx_a.gather(1, idx) * row_cot).sum()
+        res.append((norm.detach(), torch.autograd.grad(loss, [dev[k] for k in names])))
+    assert abs(res[0][0].item() - res[1][0].item()) <= 2e-5 * res[0][0].item()
+    for k, a, b in zip(names, res[0][1], res[1][1]):
+        scale = a.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-9, (k, (a - b).abs().max().item(), scale)
