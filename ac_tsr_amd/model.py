@@ -48,7 +48,9 @@ def _penalty(attack_mask, mode="local"):
     if pen is not None:
         from . import ops
         if ops.PENALTY_ROWS:
-            return torch.sqrt(pen.sum())  # gradient: a [B, nh, ceil(L/16)] cotangent into the attention backward, no dense d M
+            # gradient: a [B, nh, ceil(L/16)] cotangent into the attention backward, no dense d M.  (A zero norm -- M == 1
+            # everywhere, i.e. L = 1 -- gets a zero gradient like torch.norm's, not the square root's infinity.)
+            return torch.sqrt(pen.sum().clamp_min(1e-30))
     if attack_mask.is_cuda and attack_mask.dtype == torch.float32:
         return mask_penalty(attack_mask)
     return torch.norm(1 - attack_mask, p=2)
