@@ -97,6 +97,10 @@ def test_validation_errors_without_gpu(lib):
     assert lib.acattn_layer_tail_bwd_workspace_bytes(128, 512) == 4 * (2 * 128 * 512 + 128 * 128)
     assert lib.acattn_layer_tail_bwd_workspace_bytes(64, 256) == 4 * (2 * 64 * 256 + 64 * 64)
     assert lib.acattn_layer_tail_bwd_partial_rows_for(100, 128) == 7 and lib.acattn_layer_tail_bwd_partial_rows_for(102400, 64) == 6400
+    # the row-sum form of the mask penalty (round 3) validates before touching the device too
+    assert lib.acattn_mask_penalty_rows(None, 2, 2, 50, None, None) < 0 and b"non-NULL" in lib.acattn_last_error()
+    assert lib.acattn_attacked_loss_finish_rows(None, 4, None, 2, 16, 0.03, None, None, 0, None) < 0
+    assert lib.acattn_mask_penalty_drows(None, None, 0.5, 16, None, 2, None) < 0
     pp, po = _lib.ProjProblem(), _lib.ProjOut()
     pp.rows, pp.H, pp.G = 16, 64, 300
     assert lib.acattn_projections_fwd(C.byref(pp), C.byref(po), None) < 0 and b"gate" in lib.acattn_last_error()
