@@ -9,6 +9,8 @@ a = bench.parse()
 device = torch.device("cuda:0")
 torch.manual_seed(42)
 model = getattr(A, a.model)(A.DictConfig(bench.model_config(a)), A.ItemCount(a.items)).to(device)
+if a.model == "AcBERT4Rec":
+    model.cloze_on_device = True  # as bench.py does: the cloze batch built with tensor ops, so that the step captures
 trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model)
 model.train()
 gen = torch.Generator().manual_seed(1000)
