@@ -45,6 +45,7 @@ class FwdOut(C.Structure):
     _fields_ = [
         ("ctx_attacked", _f), ("ctx_calibrated", _f), ("attack_mask", _f), ("row_stats", _f),
         ("after_spatial", _f), ("before_spatial", _f), ("perturbed_attention", _f), ("calibrated_attention", _f),
+        ("penalty_part", _f),
     ]
 
 

@@ -86,7 +86,12 @@ int acattn_calibrated_attention_fwd(const acattn_problem* p, const acattn_fwd_ou
   if (!out->ctx_calibrated) return fail("ctx_calibrated must be non-NULL");
   if (p->adversarial && (!out->ctx_attacked || !out->attack_mask))
     return fail("adversarial forward needs ctx_attacked and attack_mask outputs");
-  const int rc = acattn_launch_fwd(*p, *out, (hipStream_t)stream);
+  acattn_penalty_written_set(false);
+  int rc = acattn_launch_fwd(*p, *out, (hipStream_t)stream);
+  // acattn_fwd_out.penalty_part: the long-sequence streaming kernel has formed the sums itself; behind every other kernel
+  // they are taken from the mask it wrote
+  if (rc == 0 && p->adversarial && out->penalty_part && !acattn_penalty_written())
+    rc = acattn_launch_penalty_rows(out->attack_mask, p->B, p->n_heads, p->L, out->penalty_part, (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;
 }

@@ -346,6 +346,9 @@ int acattn_launch_embed_bwd(const acattn_embed_problem& p, const float* dy, cons
                             float* d_table, float* d_pos_part, float* dgb_part, hipStream_t stream);
 int acattn_launch_penalty_fwd(const float* m, int64_t n, float* ws, float* norm, hipStream_t stream);
 int acattn_launch_penalty_partial(const float* m, int64_t n, float* part, hipStream_t stream);
+// acattn_fwd_out.penalty_part: did the forward launch of this host thread fill it itself? (acattn_fwd_stream.hip)
+void acattn_penalty_written_set(bool v);
+bool acattn_penalty_written();
 int acattn_launch_penalty_rows(const float* m, int B, int nh, int L, float* pen, hipStream_t stream);
 int acattn_launch_attacked_loss_finish_rows(const float* row_loss, int B, const float* const* pen, int n_masks, int count,
                                             float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream);

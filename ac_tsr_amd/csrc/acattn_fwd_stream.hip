@@ -8,6 +8,12 @@ int acattn_launch_fwd_stream_dh32(const acattn_problem& p, const acattn_fwd_out&
 int acattn_launch_fwd_stream_dh64(const acattn_problem& p, const acattn_fwd_out& o, int pre, hipStream_t stream);
 int acattn_launch_fwd_stream_dh128(const acattn_problem& p, const acattn_fwd_out& o, int pre, hipStream_t stream);
 
+namespace {
+thread_local bool g_penalty_written = false;
+}
+void acattn_penalty_written_set(bool v) { g_penalty_written = v; }
+bool acattn_penalty_written() { return g_penalty_written; }
+
 // Returns -100 when the problem is outside this kernel's domain (the caller then tries the other kernels).
 int acattn_launch_fwd_stream(const acattn_problem& p, const acattn_fwd_out& o, hipStream_t stream) {
   static const bool enabled = getenv("ACATTN_STREAM") ? atoi(getenv("ACATTN_STREAM")) != 0 : true;

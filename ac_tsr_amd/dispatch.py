@@ -30,7 +30,7 @@ _LIB.define(
     "calibrated_attention_fwd(Tensor q, Tensor k, Tensor v, Tensor? qa, Tensor? ka, Tensor? gate, Tensor key_valid, "
     "bool causal, Tensor w_order, Tensor b_order, Tensor w_dist, Tensor b_dist, Tensor scalar, int n_heads, "
     "float p_drop, int seed, Tensor? seed_tensor, bool gate_is_prob, Tensor? affine, bool adversarial) "
-    "-> (Tensor, Tensor, Tensor, Tensor)")
+    "-> (Tensor, Tensor, Tensor, Tensor, Tensor)")
 _LIB.define(
     "calibrated_attention_bwd(Tensor q, Tensor k, Tensor v, Tensor qa, Tensor ka, Tensor gate, Tensor key_valid, "
     "bool causal, Tensor w_order, Tensor b_order, Tensor w_dist, Tensor b_dist, Tensor scalar, int n_heads, "
@@ -91,18 +91,22 @@ def _fwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
         M = torch.empty(B, n_heads, L, L, device=q.device, dtype=torch.float32)
         stats = torch.empty(B, n_heads, L, _lib.NSTAT, device=q.device, dtype=torch.float32)
         out.ctx_attacked, out.attack_mask, out.row_stats = _ptr(ctx_att), _ptr(M), _ptr(stats)
+        # sum (1 - M)^2 per (sequence, head, query block): the mask penalty without another pass over M (include/acattn.h)
+        pen = torch.empty(B, n_heads, (L + 15) // 16, device=q.device, dtype=torch.float32)
+        out.penalty_part = _ptr(pen)
     else:  # the spatial-only operator writes one context; the other outputs are empty
-        ctx_att, M, stats = (q.new_empty(0) for _ in range(3))
+        ctx_att, M, stats, pen = (q.new_empty(0) for _ in range(4))
     _lib.check(_lib.load().acattn_calibrated_attention_fwd(C.byref(prob), C.byref(out), _stream()), "calibrated_attention_fwd")
-    return ctx_att, ctx_cal, M, stats
+    return ctx_att, ctx_cal, M, stats, pen
 
 
 def _fwd_meta(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
               seed_tensor, gate_is_prob, affine, adversarial):
     B, L, H = q.shape
     if adversarial:
-        return (torch.empty_like(q), torch.empty_like(q), q.new_empty(B, n_heads, L, L), q.new_empty(B, n_heads, L, _lib.NSTAT))
-    return q.new_empty(0), torch.empty_like(q), q.new_empty(0), q.new_empty(0)
+        return (torch.empty_like(q), torch.empty_like(q), q.new_empty(B, n_heads, L, L), q.new_empty(B, n_heads, L, _lib.NSTAT),
+                q.new_empty(B, n_heads, (L + 15) // 16))
+    return q.new_empty(0), torch.empty_like(q), q.new_empty(0), q.new_empty(0), q.new_empty(0)
 
 
 def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
@@ -170,7 +174,7 @@ def _setup_context(ctx, inputs, output):
     ctx.set_materialize_grads(False)
 
 
-def _backward(ctx, d_att, d_cal, d_M, _d_stats):
+def _backward(ctx, d_att, d_cal, d_M, _d_stats, d_pen=None):
     if not ctx.adversarial:
         raise _lib.AcattnError("backward of the spatial-only operator is not provided")
     q, k, v, qa, ka, gate, key_valid, w_order, b_order, w_dist, b_dist, scalar, seed_t, M, stats = ctx.saved_tensors
@@ -178,7 +182,8 @@ def _backward(ctx, d_att, d_cal, d_M, _d_stats):
     con = lambda t: None if t is None else t.contiguous()
     dq, dk, dv, dqa, dka, dgate_part, part = torch.ops.acattn.calibrated_attention_bwd(
         q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
-        seed_t if ctx.has_seed_tensor else None, gate_is_prob, M, stats, con(d_att), con(d_cal), con(d_M), None, None, False)
+        seed_t if ctx.has_seed_tensor else None, gate_is_prob, M, stats, con(d_att), con(d_cal), con(d_M), None, None, False,
+        con(d_pen))
     dh = q.shape[-1] // n_heads
     tot = part.sum(0)
     small = tot[4 * dh:]

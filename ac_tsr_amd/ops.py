@@ -223,16 +223,18 @@ class _CalibratedAttention(torch.autograd.Function):
             if cfg.adversarial and gate_logits.shape != (B, L, L):
                 # same failure as the reference's broadcast at layers.py:888 when seq_length != L
                 raise RuntimeError(f"The size of tensor a ({gate_logits.shape[-1]}) must match the size of tensor b ({L})")
-            ctx_att, ctx_cal, M, stats = torch.ops.acattn.calibrated_attention_fwd(
+            ctx_att, ctx_cal, M, stats, pen = torch.ops.acattn.calibrated_attention_fwd(
                 q, k, v, qa if cfg.adversarial else None, ka if cfg.adversarial else None,
                 gate_logits if cfg.adversarial else None, mask.key_valid, bool(mask.causal), wo.contiguous(), b_order,
                 wd.contiguous(), b_dist, scalar, nh, float(p_drop), int(seed) & 0x7FFFFFFFFFFFFFFF, seed_tensor,
                 bool(gate_is_prob), affine, bool(cfg.adversarial))
             if not cfg.adversarial:
-                ctx_att = M = stats = None
+                ctx_att = M = stats = pen = None
+            if not (PENALTY_ROWS and any(ctx.needs_input_grad[:12])):
+                pen = None
             ctx.cfg, ctx.p_drop, ctx.rnd, ctx.seed, ctx.mask, ctx.seed_tensor = cfg, p_drop, rnd, seed, mask, seed_tensor
             ctx.save_for_backward(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats)
-            return (ctx_att, ctx_cal, M, None, None, None, None, _CalibratedAttention._penalty_rows(ctx, lib, M, cfg))
+            return (ctx_att, ctx_cal, M, None, None, None, None, pen)
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
                              p_drop, rnd, seed, keep, seed_tensor, gate_is_prob, affine)
         out = FwdOut()
@@ -249,22 +251,17 @@ class _CalibratedAttention(torch.autograd.Function):
                 for name in ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention"):
                     probs[name] = torch.empty_like(M)
                     setattr(out, name, _ptr(probs[name]))
+        pen = None
+        if PENALTY_ROWS and cfg.adversarial and any(ctx.needs_input_grad[:12]):
+            pen = torch.empty(B, nh, (L + 15) // 16, device=q.device, dtype=torch.float32)
+            out.penalty_part = _ptr(pen)  # filled by the launch itself or by acattn_mask_penalty_rows behind it
         _lib.check(lib.acattn_calibrated_attention_fwd(C.byref(prob), C.byref(out), _stream()), "calibrated_attention_fwd")
         ctx.cfg, ctx.p_drop, ctx.rnd, ctx.seed, ctx.mask, ctx.seed_tensor = cfg, p_drop, rnd, seed, mask, seed_tensor
         ctx.save_for_backward(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats)
         outs = [ctx_att, ctx_cal, M] + [probs.get(n) for n in
                                         ("after_spatial", "before_spatial", "perturbed_attention", "calibrated_attention")]
         ctx.mark_non_differentiable(*[t for t in outs[3:] if t is not None])
-        return tuple(outs) + (_CalibratedAttention._penalty_rows(ctx, lib, M, cfg),)
-
-    @staticmethod
-    def _penalty_rows(ctx, lib, M, cfg):
-        if not (PENALTY_ROWS and cfg.adversarial and M is not None and any(ctx.needs_input_grad[:12])):
-            return None
-        B, nh, L, _ = M.shape
-        pen = torch.empty(B, nh, (L + 15) // 16, device=M.device, dtype=torch.float32)
-        _lib.check(lib.acattn_mask_penalty_rows(_ptr(M), B, nh, L, _ptr(pen), _stream()), "mask_penalty_rows")
-        return pen
+        return tuple(outs) + (pen,)
 
     @staticmethod
     def backward(ctx, d_att, d_cal, d_M, *_unused):

@@ -114,6 +114,11 @@ typedef struct acattn_fwd_out {
   float* before_spatial;
   float* perturbed_attention;
   float* calibrated_attention;
+  /* ABI 26, optional (adversarial form only): [B, nh, ceil(L/16)] -- acattn_mask_penalty_rows of attack_mask, i.e.
+   * sum (1 - M)^2 over each query block's rows and all L keys.  The long-sequence streaming forward forms the sums from
+   * the M block it stages for its store; for every other kernel the entry point runs acattn_mask_penalty_rows behind the
+   * launch.  Always filled when given. */
+  float* penalty_part;
 } acattn_fwd_out;
 
 typedef struct acattn_bwd_io {

@@ -152,9 +152,10 @@ def test_dispatcher_operators_are_registered_with_shape_functions():
     kv = torch.empty(B, L, dtype=torch.uint8, device="meta")
     w, b1 = torch.empty(2 * H // nh, device="meta"), torch.empty(1, device="meta")
     gate = torch.empty(B, L, L, device="meta")
-    ctx_a, ctx_c, M, stats = torch.ops.acattn.calibrated_attention_fwd(q, q, q, q, q, gate, kv, True, w, b1, w, b1, b1, nh, 0.5, 1,
+    ctx_a, ctx_c, M, stats, pen = torch.ops.acattn.calibrated_attention_fwd(q, q, q, q, q, gate, kv, True, w, b1, w, b1, b1, nh, 0.5, 1,
                                                                         None, False, None, True)
     assert ctx_a.shape == ctx_c.shape == (B, L, H) and M.shape == (B, nh, L, L) and stats.shape == (B, nh, L, _lib.NSTAT)
+    assert pen.shape == (B, nh, (L + 15) // 16)
     outs = torch.ops.acattn.calibrated_attention_bwd(q, q, q, q, q, gate, kv, True, w, b1, w, b1, b1, nh, 0.5, 1, None, False, M,
                                                      stats, q, q, M, None, None, False)
     assert [tuple(t.shape) for t in outs] == [(B, L, H)] * 5 + [(B, nh, L, L), (B * nh, 4 * (H // nh) + 4)]
