@@ -52,7 +52,9 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
         row_io.d_penalty_part = nullptr;
         const int rc_row = acattn_launch_bwd_onerow(p, row_io, true, stream);
         if (rc_row != -100) return rc_row;
-        return -1;  // the mask launch ran: the read row's chain must not be dropped silently
+        // the mask launch ran: the read row's chain must not be dropped silently
+        acattn_set_error("attention backward: the mask-only launch ran but the one-row kernel does not cover this problem (read-row chain not computed)");
+        return -1;
       }
       if (rc_mask != -100) return rc_mask;
     }

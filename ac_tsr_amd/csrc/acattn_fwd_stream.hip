@@ -28,10 +28,11 @@ int acattn_launch_fwd_stream(const acattn_problem& p, const acattn_fwd_out& o, h
   const bool gate_prob = p.adversarial && p.gate_is_prob;
   const int pre = p.affine && (gate_prob || !p.adversarial) ? 1 : 0;
   if (gate_prob && !pre) return -100;
-  // every instantiation is spill-free except dh = 64, L > 64 with the in-kernel affines (31 registers in scratch); a
-  // spilling build of this kernel produced wrong tiles at >= 2 waves per SIMD in the A/B harness (cause not
-  // established), so that corner goes to the general kernel
-  if (!pre && p.H / p.n_heads == 64 && p.L > 64) return -100;
+  // (Round 3 sent dh = 64, L > 64 without the producer extras to the general kernel: that instantiation keeps 33 registers
+  // in scratch, and two work-in-progress builds that spilled had produced wrong tiles.  Round 4 could not reproduce that
+  // with any committed source: builds forced to spill 85-109 registers at 5 and 6 waves per SIMD are bit-identical to the
+  // spill-free build at B = 128 / 256 / 512, every reload is dominated by its store (tools/scratch_dominance.py), and this
+  // instantiation equals the oracle at 3,328 waves (tests/test_hip_onehop.py, id "dh64_L200_spilling") -- DESIGN 4.1.)
   switch (p.H / p.n_heads) {
     case 16: return acattn_launch_fwd_stream_dh16(p, o, pre, stream);
     case 32: return acattn_launch_fwd_stream_dh32(p, o, pre, stream);

@@ -29,8 +29,8 @@ _LIB = torch.library.Library("acattn", "DEF")
 _LIB.define(
     "calibrated_attention_fwd(Tensor q, Tensor k, Tensor v, Tensor? qa, Tensor? ka, Tensor? gate, Tensor key_valid, "
     "bool causal, Tensor w_order, Tensor b_order, Tensor w_dist, Tensor b_dist, Tensor scalar, int n_heads, "
-    "float p_drop, int seed, Tensor? seed_tensor, bool gate_is_prob, Tensor? affine, bool adversarial) "
-    "-> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+    "float p_drop, int seed, Tensor? seed_tensor, bool gate_is_prob, Tensor? affine, bool adversarial, "
+    "bool want_penalty=True) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
 _LIB.define(
     "calibrated_attention_bwd(Tensor q, Tensor k, Tensor v, Tensor qa, Tensor ka, Tensor gate, Tensor key_valid, "
     "bool causal, Tensor w_order, Tensor b_order, Tensor w_dist, Tensor b_dist, Tensor scalar, int n_heads, "
@@ -66,21 +66,57 @@ def _problem(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist,
     return p
 
 
-def _check_inputs(*tensors):
-    for t in tensors:
-        if t is None:
-            continue
-        if not t.is_cuda:
-            raise _lib.AcattnError(f"acattn operators run only as HIP kernels on an MI355X (got a tensor on {t.device}): "
-                                   "no CPU fallback")
-        if not t.is_contiguous():
-            raise ValueError("acattn operators take contiguous tensors")
+def _check(name, t, shape, dtype, device, optional=False):
+    """The operators hand raw device pointers to the C ABI, which reads them as contiguous fp32 / uint8 / int of exactly the
+    documented shape (include/acattn.h): anything else -- an autocast bf16 tensor, an int64 validity mask, a gate of
+    another sequence length, a tensor on another GPU -- would be reinterpreted and read out of bounds.  TypeError /
+    ValueError here instead."""
+    if t is None:
+        if optional:
+            return
+        raise TypeError(f"acattn: `{name}` is required")
+    if not t.is_cuda:
+        raise _lib.AcattnError(f"acattn operators run only as HIP kernels on an MI355X (`{name}` is on {t.device}): no CPU fallback")
+    if t.device != device:
+        raise ValueError(f"acattn: `{name}` is on {t.device}, the other tensors on {device}")
+    if t.dtype != dtype:
+        raise TypeError(f"acattn: `{name}` must be {dtype} (got {t.dtype}): the kernels compute in fp32, outside autocast")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"acattn: `{name}` must have shape {tuple(shape)} (got {tuple(t.shape)})")
+    if not t.is_contiguous():
+        raise ValueError(f"acattn: `{name}` must be contiguous")
+
+
+def _check_problem(q, k, v, qa, ka, gate, key_valid, w_order, b_order, w_dist, b_dist, scalar, n_heads, seed_tensor, affine,
+                   adversarial):
+    if q.dim() != 3:
+        raise ValueError(f"acattn: `q` must be [B, L, H] (got {tuple(q.shape)})")
+    B, L, H = q.shape
+    if n_heads <= 0 or H % n_heads:
+        raise ValueError(f"The hidden size ({H}) is not a multiple of the number of attention heads ({n_heads})")  # layers.py:618-622
+    dh, dev, f32 = H // n_heads, q.device, torch.float32
+    _check("q", q, (B, L, H), f32, dev)
+    _check("k", k, (B, L, H), f32, dev)
+    _check("v", v, (B, L, H), f32, dev)
+    if adversarial:
+        _check("qa", qa, (B, L, H), f32, dev)
+        _check("ka", ka, (B, L, H), f32, dev)
+        _check("gate", gate, (B, L, L), f32, dev)
+    _check("key_valid", key_valid, (B, L), torch.uint8, dev)
+    for name, t, n in (("w_order", w_order, 2 * dh), ("w_dist", w_dist, 2 * dh), ("b_order", b_order, 1), ("b_dist", b_dist, 1),
+                       ("scalar", scalar, 1)):
+        _check(name, t, None, f32, dev)
+        if t.numel() != n:
+            raise ValueError(f"acattn: `{name}` must hold {n} value(s) (got shape {tuple(t.shape)})")
+    _check("seed_tensor", seed_tensor, (1,), torch.int64, dev, optional=True)
+    _check("affine", affine, (B, n_heads, 4, 16 * ((L + 15) // 16)), f32, dev, optional=True)
+    return B, L, H, dh
 
 
 def _fwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
-              seed_tensor, gate_is_prob, affine, adversarial):
-    _check_inputs(q, k, v, qa, ka, gate, key_valid, w_order, b_order, w_dist, b_dist, scalar, seed_tensor, affine)
-    B, L, H = q.shape
+              seed_tensor, gate_is_prob, affine, adversarial, want_penalty=True):
+    B, L, H, _ = _check_problem(q, k, v, qa, ka, gate, key_valid, w_order, b_order, w_dist, b_dist, scalar, n_heads, seed_tensor,
+                                affine, adversarial)
     prob = _problem(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop,
                     seed, seed_tensor, gate_is_prob, affine, adversarial)
     out = _lib.FwdOut()
@@ -91,9 +127,13 @@ def _fwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
         M = torch.empty(B, n_heads, L, L, device=q.device, dtype=torch.float32)
         stats = torch.empty(B, n_heads, L, _lib.NSTAT, device=q.device, dtype=torch.float32)
         out.ctx_attacked, out.attack_mask, out.row_stats = _ptr(ctx_att), _ptr(M), _ptr(stats)
-        # sum (1 - M)^2 per (sequence, head, query block): the mask penalty without another pass over M (include/acattn.h)
-        pen = torch.empty(B, n_heads, (L + 15) // 16, device=q.device, dtype=torch.float32)
-        out.penalty_part = _ptr(pen)
+        # sum (1 - M)^2 per (sequence, head, query block): the mask penalty without another pass over M (include/acattn.h).
+        # Only when a gradient can flow (evaluation / no_grad: for L <= 64 it is one more launch behind the kernel)
+        if want_penalty:
+            pen = torch.empty(B, n_heads, (L + 15) // 16, device=q.device, dtype=torch.float32)
+            out.penalty_part = _ptr(pen)
+        else:
+            pen = q.new_empty(0)
     else:  # the spatial-only operator writes one context; the other outputs are empty
         ctx_att, M, stats, pen = (q.new_empty(0) for _ in range(4))
     _lib.check(_lib.load().acattn_calibrated_attention_fwd(C.byref(prob), C.byref(out), _stream()), "calibrated_attention_fwd")
@@ -101,22 +141,32 @@ def _fwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
 
 
 def _fwd_meta(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
-              seed_tensor, gate_is_prob, affine, adversarial):
+              seed_tensor, gate_is_prob, affine, adversarial, want_penalty=True):
     B, L, H = q.shape
     if adversarial:
         return (torch.empty_like(q), torch.empty_like(q), q.new_empty(B, n_heads, L, L), q.new_empty(B, n_heads, L, _lib.NSTAT),
-                q.new_empty(B, n_heads, (L + 15) // 16))
+                q.new_empty(B, n_heads, (L + 15) // 16) if want_penalty else q.new_empty(0))
     return q.new_empty(0), torch.empty_like(q), q.new_empty(0), q.new_empty(0), q.new_empty(0)
 
 
 def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed,
               seed_tensor, gate_is_prob, attack_mask, row_stats, d_ctx_attacked, d_ctx_calibrated, d_attack_mask, read_rows,
               active_qblocks, attack_only, d_penalty_part=None):
-    _check_inputs(q, k, v, qa, ka, gate, key_valid, attack_mask, row_stats, d_ctx_attacked, d_ctx_calibrated, d_attack_mask,
-                  read_rows, active_qblocks, d_penalty_part)
+    B, L, H, dh = _check_problem(q, k, v, qa, ka, gate, key_valid, w_order, b_order, w_dist, b_dist, scalar, n_heads, seed_tensor,
+                                 None, True)
+    dev, f32 = q.device, torch.float32
+    _check("attack_mask", attack_mask, (B, n_heads, L, L), f32, dev)
+    _check("row_stats", row_stats, (B, n_heads, L, _lib.NSTAT), f32, dev)
+    _check("d_ctx_attacked", d_ctx_attacked, (B, L, H), f32, dev, optional=True)
+    _check("d_ctx_calibrated", d_ctx_calibrated, (B, L, H), f32, dev, optional=True)
+    _check("d_attack_mask", d_attack_mask, (B, n_heads, L, L), f32, dev, optional=True)
+    _check("d_penalty_part", d_penalty_part, (B, n_heads, (L + 15) // 16), f32, dev, optional=True)
+    _check("active_qblocks", active_qblocks, (B,), torch.int32, dev, optional=True)
+    if read_rows is not None:
+        if read_rows.dim() != 2 or read_rows.shape[0] != B:
+            raise ValueError(f"acattn: `read_rows` must be [B, n] (got {tuple(read_rows.shape)})")
+        _check("read_rows", read_rows, None, torch.int64, dev)
     lib = _lib.load()
-    B, L, H = q.shape
-    dh = H // n_heads
     prob = _problem(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop,
                     seed, seed_tensor, gate_is_prob, None, True)
     io = _lib.BwdIO()
@@ -162,7 +212,7 @@ _LIB.impl("calibrated_attention_bwd", _bwd_meta, "Meta")
 # ---- autograd formula of the raw forward op (a caller that bypasses ops._CalibratedAttention) ---------------------------------
 def _setup_context(ctx, inputs, output):
     (q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop, seed, seed_tensor,
-     gate_is_prob, affine, adversarial) = inputs
+     gate_is_prob, affine, adversarial) = inputs[:20]
     if not adversarial:
         ctx.adversarial = False
         return
@@ -189,7 +239,7 @@ def _backward(ctx, d_att, d_cal, d_M, _d_stats, d_pen=None):
     small = tot[4 * dh:]
     return (dq, dk, dv, dqa, dka, dgate_part.sum(1), None, None, tot[:2 * dh].view_as(w_order), small[0:1].view_as(b_order),
             tot[2 * dh:4 * dh].view_as(w_dist), small[1:2].view_as(b_dist), small[2:3].view_as(scalar), None, None, None, None,
-            None, None, None)
+            None, None, None, None)
 
 
 torch.library.register_autograd("acattn::calibrated_attention_fwd", _backward, setup_context=_setup_context, lib=_LIB)

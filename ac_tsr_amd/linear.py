@@ -185,7 +185,7 @@ class _FusedProjections(torch.autograd.Function):
         if spatial is not None and x.dim() == 3:
             w_order, b_order, w_dist, b_dist, n_heads = spatial
             B, L, H = x.shape
-            affine = _affine_workspace(x.device, B, n_heads, L)
+            affine = _affine_workspace(state, x.device, B, n_heads, L)
             keep = [t.detach().reshape(-1).contiguous() for t in (w_order, b_order, w_dist, b_dist)]
             p.w_order, p.b_order, p.w_dist, p.b_dist = (_ptr(t) for t in keep)
             p.n_heads, p.L = n_heads, L
@@ -257,20 +257,20 @@ class _FusedProjections(torch.autograd.Function):
         return (dx, *grads, None, None, None)
 
 
-_AFFINE_WS = {}
-
-
-def _affine_workspace(device, B, n_heads, L):
-    """[B, n_heads, 4, LP] zeros, ONE buffer per shape: the projections launch of a layer writes entries [0, L) of every
-    plane, the attention launch right behind it on the same stream reads them, nobody else ever does (the backward
-    recomputes from q, k and the parameters) -- so the layers of a model share it, and the padding entries [L, LP),
-    which the kernels never write but do load, stay the zeros they were allocated as."""
-    key = (device, B, n_heads, L)
-    ws = _AFFINE_WS.get(key)
+def _affine_workspace(state, device, B, n_heads, L):
+    """[B, n_heads, 4, LP] zeros: the projections launch of a layer writes entries [0, L) of every plane, the attention
+    launch right behind it on the same stream reads them, nobody else ever does (the backward recomputes from q, k and the
+    parameters) -- so the layers of ONE model share a buffer per shape, and the padding entries [L, LP), which the kernels
+    never write but do load, stay the zeros they were allocated as.  The buffer belongs to the model's StepState and is
+    never evicted (a captured hipGraph holds its address; a process-global cache with eviction was a use-after-free
+    under shape sweeps, and shared one buffer between models on different streams: ADVICE r3).  A module without a model
+    state (the frozen default) gets a fresh buffer per call."""
+    if getattr(state, "_frozen", True):
+        return torch.zeros(B, n_heads, 4, 16 * ((L + 15) // 16), device=device, dtype=torch.float32)
+    key = (str(device), B, n_heads, L)
+    ws = state.affine_ws.get(key)
     if ws is None:
-        if len(_AFFINE_WS) > 16:
-            _AFFINE_WS.clear()
-        ws = _AFFINE_WS[key] = torch.zeros(B, n_heads, 4, 16 * ((L + 15) // 16), device=device, dtype=torch.float32)
+        ws = state.affine_ws[key] = torch.zeros(B, n_heads, 4, 16 * ((L + 15) // 16), device=device, dtype=torch.float32)
     return ws
 
 

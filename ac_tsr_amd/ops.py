@@ -223,14 +223,15 @@ class _CalibratedAttention(torch.autograd.Function):
             if cfg.adversarial and gate_logits.shape != (B, L, L):
                 # same failure as the reference's broadcast at layers.py:888 when seq_length != L
                 raise RuntimeError(f"The size of tensor a ({gate_logits.shape[-1]}) must match the size of tensor b ({L})")
+            want_pen = bool(PENALTY_ROWS and cfg.adversarial and any(ctx.needs_input_grad[:12]))
             ctx_att, ctx_cal, M, stats, pen = torch.ops.acattn.calibrated_attention_fwd(
                 q, k, v, qa if cfg.adversarial else None, ka if cfg.adversarial else None,
                 gate_logits if cfg.adversarial else None, mask.key_valid, bool(mask.causal), wo.contiguous(), b_order,
                 wd.contiguous(), b_dist, scalar, nh, float(p_drop), int(seed) & 0x7FFFFFFFFFFFFFFF, seed_tensor,
-                bool(gate_is_prob), affine, bool(cfg.adversarial))
+                bool(gate_is_prob), affine, bool(cfg.adversarial), want_pen)
             if not cfg.adversarial:
                 ctx_att = M = stats = pen = None
-            if not (PENALTY_ROWS and any(ctx.needs_input_grad[:12])):
+            if not want_pen:
                 pen = None
             ctx.cfg, ctx.p_drop, ctx.rnd, ctx.seed, ctx.mask, ctx.seed_tensor = cfg, p_drop, rnd, seed, mask, seed_tensor
             ctx.save_for_backward(q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats)

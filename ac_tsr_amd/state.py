@@ -24,7 +24,7 @@ _NO_HANDOVER = _os.environ.get("ACATTN_NO_HANDOVER") == "1"  # measurement / bis
 
 class StepState:
     __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "grad_home", "_frozen",
-                 "_home_claimed")
+                 "_home_claimed", "affine_ws")
 
     def __init__(self, frozen: bool = False):
         object.__setattr__(self, "_frozen", False)
@@ -56,6 +56,11 @@ class StepState:
         # bytes) can write it there directly instead of into a fresh tensor that is copied over afterwards:
         # {parameter data_ptr: its view of the flat buffer}, set by the trainer when it has a synchronizer.
         self.grad_home = None
+        # The affine planes the projections launch hands to the attention launch behind it (linear._affine_workspace): one
+        # zero-initialised buffer per (device, B, heads, L), owned HERE -- by the model's state -- and never evicted: a
+        # captured hipGraph bakes the buffer's address into its projections and attention nodes, so the buffer has to live
+        # at least as long as any graph captured from the model, and two models of the same shape must not share one.
+        self.affine_ws = {}
         object.__setattr__(self, "_frozen", frozen)
 
     def __setattr__(self, name, value):
@@ -74,6 +79,7 @@ class StepState:
         self.pass_mode, self.prune_dead_work, self.seed_salt = st["pass_mode"], st["prune_dead_work"], st["seed_salt"]
         self.seed_tensor, self.tick = st["seed_tensor"], st["tick"]
         self.table_grad = self.grad_home = self._home_claimed = None
+        self.affine_ws = {}
         object.__setattr__(self, "_frozen", st["frozen"])
 
     def __copy__(self):
@@ -86,6 +92,7 @@ class StepState:
         new.pass_mode, new.prune_dead_work, new.seed_salt = self.pass_mode, self.prune_dead_work, self.seed_salt
         new.seed_tensor = None if self.seed_tensor is None else self.seed_tensor.clone()
         new.grad_home = None
+        new.affine_ws = {}
         memo[id(self)] = new
         return new
 

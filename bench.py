@@ -2,8 +2,9 @@
 """bench.py -- AC-SASRec training throughput on MI355X + roofline of the fused calibrated-attention kernel.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched through
-`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  Rank 0 prints ONE
-JSON line.
+`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL) -- or without a launcher, in which
+case this script starts the N ranks itself as child processes; fewer than N visible devices is an error, never a
+1-GPU number.  Rank 0 prints ONE JSON line (`n_gpus`, `rccl_ranks` = size of the process group the steps ran in).
 
   step      = one pass of the hot path over one synthetic batch: ACSASRec.calculate_loss (embedding -> LN ->
               2 calibrated encoder layers, each ONE fused HIP attention launch -> two CE losses + mask penalty),
@@ -214,6 +215,8 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None, full_len
 # --------------------------------------------------------------------------------------------------
 OTHER_CONFIGS = [
     # (label, overrides)
+    ("reference's shipped Amazon-Beauty hyper-parameters (config/amazon-beauty.yaml:33-36): AC-SASRec B=512 L=50 d=64 4 heads 3 layers inner 128",
+     dict(heads=4, layers=3, inner=128)),
     ("north_star second shape: AC-SASRec B=512 L=200 d=64 2 heads", dict(seq_len=200)),
     ("BASELINE configs[3]: AC-SASRec B=512 L=200 d=128 4 heads", dict(seq_len=200, hidden=128, heads=4, inner=512)),
     ("BASELINE configs[4]: AC-BERT4Rec (bidirectional mask) B=512 L=200 d=256 4 heads, 20000 items",
@@ -270,8 +273,10 @@ def other_configs(a, device, steps=8, warmup=3):
         gc.collect()
         torch.cuda.empty_cache()
         try:
-            r = kernel_roofline(b, device, True, iters=20, nsets=1)
-            rec["roofline"] = {k: r[k] for k in ("frac", "achieved", "avg_launch_us", "kernel", "algorithmic_bytes_per_launch")}
+            # >= 200 launches over rotating buffer sets larger than the Infinity Cache (3 sets are 0.9-3 GB here)
+            r = kernel_roofline(b, device, True, iters=70, nsets=3)
+            rec["roofline"] = {k: r[k] for k in ("frac", "achieved", "avg_launch_us", "kernel", "algorithmic_bytes_per_launch",
+                                                 "launches_timed", "buffer_sets", "item_length")}
         except Exception as e:
             rec["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         gc.collect()
@@ -341,6 +346,24 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    rehearsal = os.environ.get("ACATTN_BENCH_REHEARSAL") == "1"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher around it: measure N GPUs or fail -- never a silent 1-GPU number.
+        # The ranks are CHILD processes (torch.distributed.run); this process has not touched the GPU (device_count() does
+        # not initialise it) and only passes their output and exit code on.
+        import socket
+        import subprocess
+        have = torch.cuda.device_count()
+        if have < a.gpus and not rehearsal:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but only {have} HIP device(s) are visible "
+                             f"(ACATTN_BENCH_REHEARSAL=1 rehearses the {a.gpus}-rank path on one GPU over gloo)")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"bench.py: --gpus {a.gpus} without a launcher: starting {a.gpus} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.run(cmd).returncode)
     # A process that starts while the previous GPU process of the same box is still being torn down has (rarely: 2 of
     # ~40 back-to-back launches) found no device; wait for the device before doing anything, then fail loudly.
     for attempt in range(10):
@@ -355,9 +378,10 @@ def main():
     # Rehearsal on a box with fewer GPUs than ranks (the 8-GPU run is the driver's): ACATTN_BENCH_REHEARSAL=1 puts every
     # rank on cuda:0 and uses gloo for the collectives.  Exercises the launch / barrier / two-graph / early-reduce path;
     # its throughput means nothing.
-    rehearsal = os.environ.get("ACATTN_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but {torch.cuda.device_count()} device(s) are visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -378,6 +402,8 @@ def main():
         else:
             parallel.init_distributed("nccl")
     import torch.distributed as dist
+    backend = dist.get_backend() if world > 1 else None
+    ranks = dist.get_world_size() if world > 1 else 1
 
     if a.kernel_only:
         kinds = a.kernel_kinds.split(",")
@@ -459,6 +485,8 @@ def main():
         res = {
             "metric": "user-sequences/sec fwd+bwd, AC-SASRec L=50 d=64, 1/2/4/8 MI355X",
             "value": round(world * a.batch * a.steps / dt, 1), "unit": "user-sequences/sec", "n_gpus": world,
+            # ranks of the process group the timed steps exchanged gradients over, and its backend ("nccl" is RCCL on ROCm)
+            "rccl_ranks": ranks if backend == "nccl" else (None if world == 1 else 0), "collective_backend": backend,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "ms_per_step_median": round(per_step[len(per_step) // 2], 3), "ms_per_step_min": round(per_step[0], 3),
             "ms_per_step_max": round(per_step[-1], 3),

@@ -400,6 +400,11 @@ def main():
     if want("model_train"):
         model_case("model_train", B=6, L=50, H=64, h=2, inner=256, n_layers=2, n_items=400, seed=2, train=True)
 
+    # the hyper-parameters the reference ships for Amazon-Beauty (config/amazon-beauty.yaml:33-36: 3 layers, 4 heads -> head
+    # size 16, inner 128), BASELINE configs[0]'s dataset; eval logits + the two-pass gradients
+    if want("model_beauty"):
+        model_case("model_beauty", B=6, L=50, H=64, h=4, inner=128, n_layers=3, n_items=400, seed=5, sigma=0.05, train=False)
+
     if want("bert_gate"):
         bert_case("bert_gate", B=6, L=50, H=64, h=2, inner=256, n_layers=2, n_items=400, combine="gate", seed=3)
     if want("bert_fixed_scores"):

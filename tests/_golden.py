@@ -12,7 +12,7 @@ ENCODER_CASES = [
     "enc_gate_init", "enc_gate_stress", "enc_gate_h4", "enc_fixed_dist", "enc_fixed_order_bidir", "enc_gate_bidir",
     "enc_plain", "enc_onelevel", "enc_onelevel_trainable", "enc_anneal", "enc_leftpad", "enc_L200_h4", "enc_L200_d64_bidir", "enc_L37_ragged",
 ]
-MODEL_CASES = ["model_eval", "model_eval_stress", "model_train"]
+MODEL_CASES = ["model_eval", "model_eval_stress", "model_train", "model_beauty"]
 BERT_CASES = ["bert_gate", "bert_fixed_scores"]
 
 

@@ -102,7 +102,7 @@ def _rnds_for(c: Case, n_layers, train):
     return out
 
 
-@pytest.mark.parametrize("name", ["model_eval", "model_eval_stress", "model_train"])
+@pytest.mark.parametrize("name", ["model_eval", "model_eval_stress", "model_train", "model_beauty"])
 def test_two_pass_trainer_gradients_match_reference(name, prune_dead_work=True):
     """calculate_loss + the trainer's two backward passes: losses and every parameter gradient against
     the tensors the genuine reference produced (tests/golden/model_*.npz)."""

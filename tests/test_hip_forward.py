@@ -145,7 +145,7 @@ def _build_model(c: Case):
     return cfg, m.to(DEV)
 
 
-@pytest.mark.parametrize("name", ["model_eval", "model_eval_stress"])
+@pytest.mark.parametrize("name", ["model_eval", "model_eval_stress", "model_beauty"])
 def test_model_logits_within_1e4(name):
     c = Case(name)
     cfg, m = _build_model(c)

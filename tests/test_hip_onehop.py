@@ -65,10 +65,14 @@ def _affine_planes(t, nh):
 
 
 @pytest.mark.parametrize("B,L,H,nh,causal", [(512, 50, 64, 2, True), (512, 50, 64, 2, False), (8, 200, 128, 4, True),
-                                             (4, 200, 256, 2, False), (6, 50, 256, 2, True)],
-                         ids=["bench_shape", "bench_shape_bidirectional", "cfg4_shape", "dh128_L200_bidirectional", "dh128_L50"])
+                                             (4, 200, 256, 2, False), (6, 50, 256, 2, True), (128, 200, 128, 2, True)],
+                         ids=["bench_shape", "bench_shape_bidirectional", "cfg4_shape", "dh128_L200_bidirectional", "dh128_L50",
+                              "dh64_L200_spilling"])
 @pytest.mark.parametrize("extras", [False, True], ids=["in_kernel", "producer_extras"])
 def test_streaming_forward_matches_oracle_in_one_hop(B, L, H, nh, causal, extras):
+    """id dh64_L200_spilling [r4]: head size 64, L > 64, in-kernel affines is the one instantiation of the streaming forward
+    that keeps registers in scratch (33; tests/test_abi_cpu.py pins that set); 128 x 2 x 13 = 3,328 waves are more than two
+    per SIMD, the occupancy at which round 3's work-in-progress builds went wrong."""
     t, kv, lens, g = _problem(B, L, H, nh, seed=101, causal=causal)
     dev = {k: v.to(DEV) for k, v in t.items()}
     cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
@@ -283,6 +287,58 @@ def test_dispatcher_operators_equal_the_direct_c_abi_path():
                           test_utils=("test_schema", "test_faketensor"))
 
 
+def test_dispatcher_operators_reject_what_the_c_abi_would_misread():
+    """The operators hand raw pointers to the C ABI (fp32 / uint8, exact shapes): a half-precision activation (autocast), an
+    int64 validity mask, a gate or affine of another length, a tensor on the host must raise, not be reinterpreted
+    (ADVICE r3).  The evaluation form (want_penalty=False) returns an empty penalty tensor."""
+    from ac_tsr_amd import dispatch  # noqa: F401
+    B, L, H, nh = 4, 50, 64, 2
+    t, kv, lens, g = _problem(B, L, H, nh, seed=9)
+    dev = {k: v.to(DEV) for k, v in t.items()}
+    kvd = kv.to(DEV)
+
+    def call(**over):
+        a = dict(q=dev["q"], k=dev["k"], v=dev["v"], qa=dev["qa"], ka=dev["ka"], gate=dev["gl"], key_valid=kvd, affine=None,
+                 w_order=dev["w_order"].reshape(-1), want_penalty=True)
+        a.update(over)
+        return torch.ops.acattn.calibrated_attention_fwd(
+            a["q"], a["k"], a["v"], a["qa"], a["ka"], a["gate"], a["key_valid"], True, a["w_order"], dev["b_order"],
+            dev["w_dist"].reshape(-1), dev["b_dist"], dev["scalar"], nh, 0.5, 11, None, False, a["affine"], True, a["want_penalty"])
+
+    out = call()
+    assert out[4].shape == (B, nh, 4)
+    assert call(want_penalty=False)[4].numel() == 0
+    with pytest.raises(TypeError):
+        call(q=dev["q"].bfloat16())
+    with pytest.raises(TypeError):
+        call(qa=dev["qa"].half())
+    with pytest.raises(TypeError):
+        call(key_valid=kvd.long())
+    with pytest.raises(ValueError):
+        call(gate=dev["gl"][:, :, :48].contiguous())
+    with pytest.raises(ValueError):
+        call(key_valid=kvd[:, :48].contiguous())
+    with pytest.raises(ValueError):
+        call(affine=torch.zeros(B, nh, 4, 48, device=DEV))
+    with pytest.raises(ValueError):
+        call(w_order=dev["w_order"].reshape(-1)[:10].contiguous())
+    with pytest.raises(ValueError):
+        call(k=dev["k"].transpose(0, 1).contiguous().transpose(0, 1))
+    with pytest.raises(_lib.AcattnError):
+        call(v=t["v"])
+    M, stats = out[2], out[3]
+    with pytest.raises(TypeError):
+        torch.ops.acattn.calibrated_attention_bwd(
+            dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev["gl"], kvd, True, dev["w_order"].reshape(-1), dev["b_order"],
+            dev["w_dist"].reshape(-1), dev["b_dist"], dev["scalar"], nh, 0.5, 11, None, False, M, stats, dev["q"].double(), None, None,
+            None, None, False, None)
+    with pytest.raises(ValueError):
+        torch.ops.acattn.calibrated_attention_bwd(
+            dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], dev["gl"], kvd, True, dev["w_order"].reshape(-1), dev["b_order"],
+            dev["w_dist"].reshape(-1), dev["b_dist"], dev["scalar"], nh, 0.5, 11, None, False, M[:, :1].contiguous(), stats, dev["q"], None,
+            None, None, None, False, None)
+
+
 @pytest.mark.parametrize("rich", ["fixed", "trainable"])
 @pytest.mark.parametrize("B,L,H,nh,causal", [(3, 100, 64, 2, True), (2, 200, 128, 4, True), (2, 200, 64, 2, False), (3, 130, 64, 4, True)],
                          ids=["L100", "L200_cfg4_heads", "L200_bidirectional_atomics", "L130_dh16"])
@@ -359,3 +415,86 @@ def test_penalty_row_sums_carry_the_mask_penalty_gradient(B, L, H, nh, causal, r
     for k, a, b in zip(names, res[0][1], res[1][1]):
         scale = a.abs().max().item()
         assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-9, (k, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("causal", [True, False], ids=["causal", "bidirectional"])
+@pytest.mark.parametrize("p_drop", [0.5, 0.0])
+def test_spatial_only_forward_with_producer_planes_matches_oracle_at_the_bench_shape(causal, p_drop):
+    """BASELINE configs[1] as bench.py times it (roofline_spatial_only): acattn_fwd_stream_kernel<32,4,false,*,true> --
+    spatial calibrator only (layers.py:705-740, contract A'), affine planes from the producer, B = 512, lengths ~ U{1..L}
+    incl. a left-padded sequence: ctx = dropout(after_spatial) . V against the oracle, fed the kernel's own keep draws."""
+    B, L, H, nh = 512, 50, 64, 2
+    t, kv, lens, g = _problem(B, L, H, nh, seed=404, causal=causal, left_pad=True)
+    dev = {k: v.to(DEV) for k, v in t.items()}
+    cfg = A.AttentionConfig(n_heads=nh, adversarial=False)
+    mask = A.StructuredMask(kv.to(DEV), causal=causal)
+    kw = {k: dev[k] for k in ("w_order", "b_order", "w_dist", "b_dist", "scalar")}
+    seed = 31337
+    lib = _lib.load()
+    lib.acattn_select_forward_kernel(_lib.FWD_STREAM)
+    try:
+        none, ctx, M, _ = A.calibrated_attention(dev["q"], dev["k"], dev["v"], None, None, None, mask, cfg, p_drop=p_drop, seed=seed,
+                                                 affine=_affine_planes(t, nh).to(DEV), **kw)
+        _, ctx_in, _, _ = A.calibrated_attention(dev["q"], dev["k"], dev["v"], None, None, None, mask, cfg, p_drop=p_drop, seed=seed, **kw)
+    finally:
+        lib.acattn_select_forward_kernel(_lib.FWD_AUTO)
+    assert M is None and none is None
+    ocfg = O.EncoderCfg(n_layers=1, n_heads=nh, hidden_size=H, inner_size=4 * H, combine_option="gate", seq_length=L,
+                        attn_dropout_prob=p_drop)
+    keep_after = None
+    if p_drop > 0:
+        keep_after = A.materialize_randomness(B, nh, L, seed, p_drop, DEV).keep_after.cpu().float()
+    with torch.no_grad():
+        zeros = torch.zeros(B, nh, L, L)
+        after = O.core_from_projected(t["q"], t["k"], t["v"], t["q"], t["k"], t["gl"], _oracle_mask(kv, causal), t["w_order"],
+                                      t["b_order"], t["w_dist"], t["b_dist"], t["scalar"], ocfg, zeros, keep_after=keep_after,
+                                      materialize=False)["after"]
+        v = O._heads(t["v"], nh).permute(0, 2, 1, 3)
+        expect = O.context_only(after, v)
+    assert (ctx.cpu() - expect).abs().max().item() <= 1e-4
+    assert (ctx_in.cpu() - expect).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("where", ["q", "k", "v", "qa", "gate"])
+@pytest.mark.parametrize("L,extras", [(50, True), (50, False), (200, True)], ids=["L50_extras", "L50_in_kernel", "L200_extras"])
+def test_a_nan_in_the_inputs_reaches_the_outputs_of_the_streaming_forward(where, L, extras):
+    """The reference's only failure detector is _check_nan on the losses (recbole/trainer/trainer.py:763-765).  The
+    streaming forward's translation units are built with -fno-honor-nans (csrc/Makefile: it removes canonicalising
+    v_max x, x in front of the row maxima); that must not let a non-finite activation turn into plausible numbers: a NaN
+    in a VALID row of any input has to come out as a NaN in the context rows that row feeds."""
+    B, H, nh = 64, 64, 2
+    t, kv, lens, g = _problem(B, L, H, nh, seed=77)
+    kv[:] = 1  # every position valid: the poisoned row is visible to itself and to every later query
+    b, i = 5, 3
+    if where == "gate":
+        t["gl"][b, i, :] = float("nan")
+    else:
+        t[where][b, i, 7] = float("nan")
+    dev = {k: v.to(DEV) for k, v in t.items()}
+    cfg = A.AttentionConfig(n_heads=nh, combine_option="gate")
+    mask = A.StructuredMask(kv.to(DEV), causal=True)
+    kw = {k: dev[k] for k in ("w_order", "b_order", "w_dist", "b_dist", "scalar")}
+    gate = dev["gl"]
+    if extras:
+        kw.update(affine=torch.nan_to_num(_affine_planes(t, nh)).to(DEV) if where not in ("q", "k") else _affine_planes(t, nh).to(DEV),
+                  gate_is_prob=True)
+        gate = torch.sigmoid(dev["gl"])
+    lib = _lib.load()
+    lib.acattn_select_forward_kernel(_lib.FWD_STREAM)
+    try:
+        ctx_a, ctx_c, M, _ = A.calibrated_attention(dev["q"], dev["k"], dev["v"], dev["qa"], dev["ka"], gate, mask, cfg,
+                                                    p_drop=0.0, seed=5, **kw)
+    finally:
+        lib.acattn_select_forward_kernel(_lib.FWD_AUTO)
+    torch.cuda.synchronize()
+    # head 0 holds column 7; query row i sees key i under the causal mask, so row i of the poisoned head is the witness
+    if where in ("q", "k", "v", "gate"):
+        assert torch.isnan(ctx_c[b, i, :H // nh]).any(), "NaN swallowed on the calibrated branch"
+    if where in ("q", "k", "v"):
+        assert torch.isnan(ctx_a[b, i, :H // nh]).any(), "NaN swallowed on the attacked branch"
+    if where == "qa":
+        assert torch.isnan(M[b, 0, i]).any() and torch.isnan(ctx_a[b, i, :H // nh]).any()
+    # and nothing leaks into other sequences
+    other = torch.ones(B, dtype=torch.bool)
+    other[b] = False
+    assert torch.isfinite(ctx_c[other.to(DEV)]).all() and torch.isfinite(ctx_a[other.to(DEV)]).all()

@@ -70,7 +70,7 @@ static float* dev_copy(const std::vector<float>& h) {
 }
 
 int main(int argc, char** argv) {
-  int B = 512, L = 50, H = 64, nh = 2, adv = 1, rounds = 12, iters = 60, nsets = 6, stamps = 0, full_len = 0, balance = 0, causal = 1;
+  int B = 512, L = 50, H = 64, nh = 2, adv = 1, rounds = 12, iters = 60, nsets = 6, stamps = 0, full_len = 0, balance = 0, causal = 1, where = 0;
   float p_drop = 0.5f, wscale = 0.02f;
   std::vector<std::string> libs;
   for (int i = 1; i < argc; ++i) {
@@ -87,6 +87,7 @@ int main(int argc, char** argv) {
     else if (is("-full")) full_len = atoi(argv[++i]);
     else if (is("-balance")) balance = atoi(argv[++i]);
     else if (is("-causal")) causal = atoi(argv[++i]);
+    else if (is("-where")) where = atoi(argv[++i]);
     else if (is("-pdrop")) p_drop = atof(argv[++i]);
     else if (is("-wscale")) wscale = atof(argv[++i]);
     else libs.push_back(argv[i]);
@@ -218,6 +219,37 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < n_lh; ++i) { if (!(cur_c[i] == cur_c[i])) ++nan; dc = std::max(dc, (double)fabsf(cur_c[i] - ref_c[i])); sc += fabs(cur_c[i]); }
     for (size_t i = 0; i < cur_m.size(); ++i) dm = std::max(dm, (double)fabsf(cur_m[i] - ref_m[i]));
     printf("variant %zu %-40s  max|ctx_cal - v0| = %.3e  max|M - v0| = %.3e  mean|ctx| = %.4f nan=%zu\n", v, libs[v].c_str(), dc, dm, sc / n_lh, nan);
+    if (where && v > 0) {  // where the outputs differ from variant 0: (b, head, row, key) of M, (b, row, column) of the contexts
+      size_t shown = 0, bad = 0;
+      std::vector<size_t> by_qb(16, 0), by_tile(16, 0);
+      for (size_t i = 0; i < cur_m.size(); ++i) {
+        if (fabsf(cur_m[i] - ref_m[i]) <= 1e-5f) continue;
+        const size_t j = i % L, r = (i / L) % L, h = (i / ((size_t)L * L)) % nh, b = i / ((size_t)L * L * nh);
+        ++bad; ++by_qb[r >> 4]; ++by_tile[j >> 4];
+        if (shown++ < 12) printf("    M[b=%zu h=%zu i=%zu j=%zu] = %.6g  (v0 %.6g)\n", b, h, r, j, cur_m[i], ref_m[i]);
+      }
+      printf("    M: %zu of %zu elements differ; by query block:", bad, cur_m.size());
+      for (int q = 0; q < (L + 15) / 16; ++q) printf(" %zu", by_qb[q]);
+      printf("; by key tile:");
+      for (int q = 0; q < (L + 15) / 16; ++q) printf(" %zu", by_tile[q]);
+      printf("\n");
+      for (int which = 0; which < (adv ? 2 : 1); ++which) {
+        const std::vector<float>&cu = which ? cur_a : cur_c, &re = which ? ref_a : ref_c;
+        size_t nb = 0, sh = 0;
+        std::vector<size_t> qb(16, 0);
+        std::vector<char> seqbad(B, 0);
+        for (size_t i = 0; i < n_lh; ++i) {
+          if (fabsf(cu[i] - re[i]) <= 1e-5f && cu[i] == cu[i]) continue;
+          const size_t col = i % H, r = (i / H) % L, b = i / ((size_t)H * L);
+          ++nb; ++qb[r >> 4]; seqbad[b] = 1;
+          if (sh++ < 12) printf("    %s[b=%zu i=%zu col=%zu] = %.6g  (v0 %.6g)\n", which ? "ctx_att" : "ctx_cal", b, r, col, cu[i], re[i]);
+        }
+        size_t nseq = 0; for (char c2 : seqbad) nseq += c2;
+        printf("    %s: %zu elements differ in %zu sequences; by query block:", which ? "ctx_att" : "ctx_cal", nb, nseq);
+        for (int q = 0; q < (L + 15) / 16; ++q) printf(" %zu", qb[q]);
+        printf("\n");
+      }
+    }
   }
   std::vector<std::vector<float>> us(fns.size());
   for (int r = -1; r < rounds; ++r) {
