@@ -24,7 +24,7 @@ _NO_HANDOVER = _os.environ.get("ACATTN_NO_HANDOVER") == "1"  # measurement / bis
 
 class StepState:
     __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "grad_home", "_frozen",
-                 "_home_claimed", "affine_ws")
+                 "_home_claimed", "affine_ws", "combined")
 
     def __init__(self, frozen: bool = False):
         object.__setattr__(self, "_frozen", False)
@@ -61,6 +61,8 @@ class StepState:
         # captured hipGraph bakes the buffer's address into its projections and attention nodes, so the buffer has to live
         # at least as long as any graph captured from the model, and two models of the same shape must not share one.
         self.affine_ws = {}
+        # combined.CombinedWalk while a single-pass combined backward runs (trainer, opt-in), else None
+        self.combined = None
         object.__setattr__(self, "_frozen", frozen)
 
     def __setattr__(self, name, value):
@@ -80,6 +82,7 @@ class StepState:
         self.seed_tensor, self.tick = st["seed_tensor"], st["tick"]
         self.table_grad = self.grad_home = self._home_claimed = None
         self.affine_ws = {}
+        self.combined = None
         object.__setattr__(self, "_frozen", st["frozen"])
 
     def __copy__(self):
@@ -93,6 +96,7 @@ class StepState:
         new.seed_tensor = None if self.seed_tensor is None else self.seed_tensor.clone()
         new.grad_home = None
         new.affine_ws = {}
+        new.combined = None
         memo[id(self)] = new
         return new
 

@@ -26,9 +26,21 @@ def is_attack_param(name: str) -> bool:
 class AttackSASRecTrainer:
     """Minimal trainer: optimizer construction (trainer.py:590-615: Adam by default) and the epoch loop."""
 
-    def __init__(self, config, model, grad_sync=None):
+    def __init__(self, config, model, grad_sync=None, combined_backward: Optional[bool] = None):
+        """`combined_backward` (or config key of that name; default False = the reference's protocol): ONE walk of the
+        autograd graph carries the cotangents of both losses (ac_tsr_amd/combined.py) instead of two walks of the same
+        graph (trainer.py:672-686).  Same losses, same gradients on every parameter, same update."""
         self.config = config
         self.model = model
+        if combined_backward is None:
+            try:
+                combined_backward = bool(config['combined_backward']) if config is not None else False
+            except KeyError:
+                combined_backward = False
+        self.combined_backward = bool(combined_backward)
+        if self.combined_backward:
+            from .combined import instrument_package
+            instrument_package()  # before any forward whose graph will be walked
         self.learner = (config['learner'] or 'adam') if config is not None else 'adam'
         self.learning_rate = (config['learning_rate'] or 1e-3) if config is not None else 1e-3
         self.weight_decay = (config['weight_decay'] or 0.0) if config is not None else 0.0
@@ -108,7 +120,55 @@ class AttackSASRecTrainer:
             with self.state.attack_pass():
                 attacked_loss.backward(inputs=self._attack)
 
+    def _forward(self, interaction, check_nan: bool = False):
+        if self._seed_t is not None:
+            self._seed_t += 1
+        if self.grad_sync is not None:
+            self.grad_sync.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        attacked_loss, calibrated_loss = self.model.calculate_loss(interaction)
+        if check_nan:
+            if attacked_loss is not None:
+                self._check_nan(attacked_loss)
+            self._check_nan(calibrated_loss)
+        return attacked_loss, calibrated_loss
+
+    def _combined_pass(self, interaction, check_nan: bool = False):
+        """Forward + ONE backward walk for both losses (combined.py).  The walk is `calibrated_loss.backward` over the
+        non-attack leaves -- the engine's own gradients are the calibrated set -- with the attacked set travelling beside
+        it; the attack transforms receive the attacked set's gradients directly."""
+        attacked_loss, calibrated_loss = self._forward(interaction, check_nan)
+        self.combined_backward_walk(attacked_loss, calibrated_loss)
+        return attacked_loss, calibrated_loss
+
+    def combined_backward_walk(self, attacked_loss, calibrated_loss):
+        """The single walk itself, for losses of a forward that ran AFTER this trainer was built with
+        combined_backward=True (the nodes are instrumented then).  Accumulates into .grad like the two walks do."""
+        from .combined import CombinedWalk
+        if not self.combined_backward:
+            raise RuntimeError("build the trainer with combined_backward=True before the forward whose graph is walked")
+        walk = CombinedWalk(self.state, self._attack)
+        with self.state.calibrated_pass():
+            self.state.combined = walk
+            try:
+                walk.prefix(attacked_loss, calibrated_loss)
+                calibrated_loss.backward(inputs=self._others)
+                walk.finish()
+            finally:
+                self.state.combined = None
+        self.last_walk_stats = walk.stats
+
     def _eager_step(self, interaction, check_nan: bool = False):
+        if self.combined_backward:
+            attacked_loss, calibrated_loss = self._combined_pass(interaction, check_nan)
+            if self.grad_sync is not None:
+                self.grad_sync.all_reduce()  # one walk: every gradient is final at the same time, one exchange
+            self.optimizer.step()
+            return attacked_loss, calibrated_loss
+        return self._two_pass_step(interaction, check_nan)
+
+    def _two_pass_step(self, interaction, check_nan: bool = False):
         """One batch of trainer.py:660-687.  With a gradient synchronizer the all-reduce of everything but the attack
         transforms (the item table: 99.9 % of the bytes) starts between the passes and pass 2 runs under it."""
         attacked_loss, calibrated_loss = self._pass_one(interaction, check_nan)
@@ -160,7 +220,16 @@ class AttackSASRecTrainer:
         if debug_dump:
             graph.enable_debug_mode()  # keeps the captured hipGraph so that debug_dump can print it (diagnosis only)
         self._graph2 = None
-        if self.grad_sync is None:
+        if self.combined_backward:
+            with torch.cuda.graph(graph):
+                outs = self._combined_pass(self._static_in)
+                if self.grad_sync is None:
+                    self.optimizer.step()
+                else:
+                    self.grad_sync.pack("all")
+            if self.grad_sync is not None:
+                self.grad_sync.attach()
+        elif self.grad_sync is None:
             with torch.cuda.graph(graph):
                 outs = self._pass_one(self._static_in)
                 self._pass_two(outs[0])
