@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 MAX_MASKS = 8  # ACATTN_MAX_MASKS
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
@@ -56,7 +56,7 @@ class BwdIO(C.Structure):
         ("dq", _f), ("dk", _f), ("dv", _f), ("dqa", _f), ("dka", _f), ("dgate_logits", _f),
         ("dw_order_part", _f), ("dw_dist_part", _f), ("dsmall_part", _f), ("part_stride", C.c_int32),
         ("active_qblocks", _f), ("attack_only", C.c_int32), ("workspace", _f), ("read_rows", _f),
-        ("n_read_rows", C.c_int32), ("d_penalty_part", _f),
+        ("n_read_rows", C.c_int32), ("d_penalty_part", _f), ("dgate_summed", C.c_int32),
     ]
 
 
@@ -131,6 +131,7 @@ WGRAD_MAX_GROUP = 8
 # name -> (restype, argtypes); must list every symbol include/acattn.h declares (tests check this)
 SYMBOLS = {
     "acattn_abi_version": (C.c_int, []),
+    "acattn_calibrated_attention_bwd_gate_summed": (C.c_int, [C.POINTER(Problem), C.POINTER(BwdIO)]),
     "acattn_last_error": (C.c_char_p, []),
     "acattn_fwd_algorithmic_bytes": (C.c_int64, [C.POINTER(Problem)]),
     "acattn_calibrated_attention_fwd": (C.c_int, [C.POINTER(Problem), C.POINTER(FwdOut), C.c_void_p]),

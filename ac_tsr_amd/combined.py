@@ -48,7 +48,22 @@ def instrument(*classes) -> None:
 
         def forward(ctx, *args, _fwd=fwd):
             ctx._acattn_tensor_args = tuple(isinstance(a, torch.Tensor) for a in args)
-            return _fwd(ctx, *args)
+            # (the node's materialize_grads flag cannot be read back from Python: record what forward sets)
+            ctx._acattn_materialize = True
+            setter = ctx.set_materialize_grads
+
+            def record(value, _ctx=ctx, _setter=setter):
+                _ctx._acattn_materialize = bool(value)
+                _setter(value)
+
+            ctx.set_materialize_grads = record
+            try:
+                return _fwd(ctx, *args)
+            finally:  # back to the class method (no reference cycle through the closure)
+                try:
+                    del ctx.set_materialize_grads
+                except AttributeError:
+                    pass
 
         def backward(ctx, *grads, _bwd=bwd):
             walk = getattr(getattr(ctx, "state", None), "combined", None)
@@ -132,7 +147,7 @@ class CombinedWalk:
         """One node's backward, by hand, for the att set."""
         with torch.no_grad(), self._by_hand(), self._attack():
             if isinstance(fn, BackwardCFunction):
-                if getattr(fn, "materialize_grads", True):
+                if getattr(fn, "_acattn_materialize", True):
                     grads = [g if g is not None else self._zeros_for(fn, i) for i, g in enumerate(grads)]
                 out = fn.apply(*grads)
             else:
@@ -180,7 +195,7 @@ class CombinedWalk:
             res_att = None
             if g_att:
                 att = [g_att.get(i) for i in range(len(g_cal))]
-                if getattr(ctx, "materialize_grads", True):
+                if getattr(ctx, "_acattn_materialize", True):
                     att = [a if a is not None else (torch.zeros_like(c) if c is not None else self._zeros_for(ctx, i))
                            for i, (a, c) in enumerate(zip(att, g_cal))]
                 with torch.no_grad(), self._attack():

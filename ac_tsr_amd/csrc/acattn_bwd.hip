@@ -23,7 +23,35 @@ int acattn_bwd_kernel_choice(int which) {
   return old;
 }
 
+bool acattn_bwd_onerow_applies(const acattn_problem& p, const acattn_bwd_io& io);
+
+namespace {
+bool onerow_split_applies(const acattn_problem& p, const acattn_bwd_io& io) {
+  static const bool split = getenv("ACATTN_ONEROW_SPLIT") ? atoi(getenv("ACATTN_ONEROW_SPLIT")) != 0 : true;
+  if (!(split && (io.d_attack_mask || io.d_penalty_part) && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.attack_only && p.L <= 64))
+    return false;
+  const int dh = p.n_heads > 0 ? p.H / p.n_heads : 0;
+  if (dh != 16 && dh != 32 && dh != 64) return false;  // the mask-only launch is the row-resident kernel's (acattn_launch_bwd_fast)
+  acattn_bwd_io row_io = io;
+  row_io.d_attack_mask = nullptr;
+  row_io.d_penalty_part = nullptr;
+  return acattn_bwd_onerow_applies(p, row_io);
+}
+}  // namespace
+
+// acattn_bwd_io.dgate_summed: will the launch write the head-summed gate gradient?  (the one-row form, alone or behind the
+// mask-only launch of the split)
+bool acattn_bwd_gate_summed(const acattn_problem& p, const acattn_bwd_io& io) {
+  if (g_bwd_kernel != ACATTN_BWD_AUTO || !io.dgate_logits) return false;
+  return acattn_bwd_onerow_applies(p, io) || onerow_split_applies(p, io);
+}
+
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
+  if (io.dgate_summed && !acattn_bwd_gate_summed(p, io)) {
+    acattn_set_error("attention backward: dgate_summed requested but this launch does not take the one-row form "
+                     "(ask acattn_calibrated_attention_bwd_gate_summed first)");
+    return -1;
+  }
   // training hot paths (structured mask, counter RNG, gate, two_level), -100 = not applicable:
   //   L <= 64: the row-resident kernel (acattn_bwd_fast.hip, one recomputation, a query block's row in registers).
   //     Inside the training step at B = 512, L = 50 its four calls take 71 / 108 / 103 / 57 us against 80 / 112 / 110 /
@@ -57,6 +85,10 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
         return -1;
       }
       if (rc_mask != -100) return rc_mask;
+    }
+    if (io.dgate_summed) {  // (unreachable while acattn_bwd_gate_summed mirrors the two one-row forms above)
+      acattn_set_error("attention backward: dgate_summed was accepted but no one-row form ran");
+      return -1;
     }
   }
   const bool short_rows = p.L <= 64;

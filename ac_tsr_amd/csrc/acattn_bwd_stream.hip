@@ -193,6 +193,32 @@ __device__ __forceinline__ void tile_backward(const Tile& T, const Consts& K, co
   dsc = hsum(dS * (T.df * T.df)) * (-K.sc);
 }
 
+// [r4] A (query block, key tile) pair whose rows carry NO context cotangent (acattn_bwd_io.read_rows / active_qblocks: in the
+// last layer every block but the one with the read position): what reaches it is the mask's cotangent alone -- the
+// penalty's d M = 2 d_pen (M - 1) (acsasrec.py:131-137) and / or a dense d M -- and d M only flows back through
+// M = dropout(softmax(Sa / sqrt(dh) + mask)) (layers.py:664-672): du = dv = dw = 0 in tile_backward, so dS = 0, the gate
+// and the spatial calibrator receive nothing, and of the tile only Mt / M have to be rebuilt (one product, four
+// exponentials, the keep bits) instead of all seven probability tensors and the random numbers.
+// `Mt`: softmax(y) before dropout; `dM`: the cotangent of Mt's argument side, i.e. keep(d M_out * keep_scale).
+template <class RowT>
+__device__ __forceinline__ void mask_tile(const RowT& R, const Consts& K, const f4 aM, const int t, const int g, const uint32_t eb4,
+                                          const f4 dMext, const float dpen2, f4& Mt, f4& dM) {
+  f4 mk4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mk4[r] = and_bits(ACATTN_MASK_FILL * kLog2e, ~sbit(eb4, r));
+  const f4 y = aM * K.scale2 + mk4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Mt[r] = ex2(y[r] - R.ly2);
+  uint32_t km = 0xFu;
+  if (K.has_drop) km = rng_group(K.rkey, R.rng_row, (uint32_t)(4 * t + g), K.p_drop).keep_mask;  // (the normals fold away)
+  f4 M = Mt * K.keep_scale;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) M[r] = keep_and(M[r], km, r);
+  dM = dMext + (M - 1.0f) * dpen2;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dM[r] = keep_and(dM[r] * K.keep_scale, km, r);
+}
+
 // 4 floats of a [.., L] row at key offset j0 (rows with L % 4 != 0 are only dword aligned; the last group is ragged)
 __device__ __forceinline__ f4 load_seg(const float* row, int j0, int L, bool ok) {
   f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -297,6 +323,35 @@ __device__ __forceinline__ void load_row(const acattn_problem& P, const acattn_b
   R.lu2 = (s0[2] - sh) * kLog2e;
   R.lv2 = (s0[3] - sh) * kLog2e;
   R.lw2 = (s4v - sh) * kLog2e;
+  R.rng_row = (uint32_t)(bh * L + R.i);
+}
+
+// What the mask-only path needs of a query row: the attack query fragment, the normaliser of M, the flags.
+template <int DH>
+struct MaskRow {
+  float qaf[DH / 4];
+  float ly2;
+  int i;
+  bool row_ok, dead;
+  uint32_t rng_row;
+};
+template <int DH>
+__device__ __forceinline__ void load_mask_row(const acattn_problem& P, const acattn_bwd_io& IO, const KeyFlags& F, size_t rowbase,
+                                              size_t bh, int hoff, int qb, int c, int g, MaskRow<DH>& R) {
+  constexpr int KS = DH / 4;
+  const int L = P.L, H = P.H;
+  R.i = 16 * qb + c;
+  R.row_ok = R.i < L;
+  const size_t off = (rowbase + (R.row_ok ? R.i : 0)) * H + hoff + KS * g;
+#pragma unroll
+  for (int s4 = 0; s4 < KS / 4; ++s4) {
+    const f4 ta = *(const f4*)(P.qa + off + 4 * s4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) R.qaf[4 * s4 + e] = R.row_ok ? ta[e] : 0.f;
+  }
+  R.dead = P.causal ? F.first_valid > R.i : !F.any_valid;
+  const float sh = R.dead ? ACATTN_MASK_FILL : 0.f;
+  R.ly2 = (IO.row_stats[(bh * L + (R.row_ok ? R.i : 0)) * ACATTN_NSTAT + 1] - sh) * kLog2e;
   R.rng_row = (uint32_t)(bh * L + R.i);
 }
 
@@ -407,6 +462,67 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
   }
 
   const Consts K = make_consts(P, DH);
+  const int i0 = 16 * qb;
+  const bool rows_see_a_key = causal ? F.first_valid <= i0 : F.any_valid;
+  const int nt = rows_see_a_key ? min(causal ? min(nT, qb + 1) : nT, F.nt_valid) : nT;
+#ifndef ACATTN_BWD_NO_MASK_ONLY
+  if (!qblock_has_ctx(IO, b, qb)) {
+    // ---- [r4] mask-only block (see mask_tile): s M in sweep 1, d Sa -> dqa in sweep 2; dq, the gate rows and the row scalars
+    // of the context chain are zero; no parameter partials ---------------------------------------------------------------------
+    const float* dmrow_m = IO.d_attack_mask ? IO.d_attack_mask + prow : nullptr;
+    const float dpen2_m = IO.d_penalty_part ? 2.0f * IO.d_penalty_part[(size_t)bh * nT + qb] : 0.f;
+    auto tile = [&](int t, f4& Mt, f4& dM) {
+      f4 ka4[DT];
+      row_frag<DH>(P.ka, rowbase, H, hoff, 16 * t, L, c, g, ka4);
+      f4 aM = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < KS / 4; ++s4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aM = mfma16(ka4[s4][e], R.qaf[4 * s4 + e], aM);
+      uint32_t eb4, ab4;
+      tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
+      const f4 dMext = dmrow_m ? load_seg(dmrow_m, 16 * t + 4 * g, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
+      mask_tile(R, K, aM, t, g, eb4, dMext, dpen2_m, Mt, dM);
+    };
+    float s_m = 0.f;
+    for (int t = 0; t < nt; ++t) {
+      f4 Mt, dM;
+      tile(t, Mt, dM);
+      s_m += hsum(Mt * dM);
+    }
+    const float sM = quad_sum(s_m);
+    if (R.row_ok && g == 0) {
+      *(f4*)wrow = f4{0.f, 0.f, 0.f, 0.f};
+      *(f4*)(wrow + 4) = f4{sM, 0.f, 0.f, 0.f};
+    }
+    f4 oqa[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oqa[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nt; ++t) {
+      f4 Mt, dM;
+      tile(t, Mt, dM);
+      const f4 dSa = (Mt * (dM - sM)) * K.inv_sqrt;
+      float kac[4][DT];
+      col_frag<DH>(P.ka, rowbase, H, hoff, 16 * t, L, c, g, kac);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oqa[dt] = mfma16(kac[r][dt], dSa[r], oqa[dt]);
+    }
+    if (R.row_ok) {
+      const f4 z = {0.f, 0.f, 0.f, 0.f};
+      const uint32_t off = ((uint32_t)rowbase + R.i) * H + hoff + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        if (full) *(f4*)(IO.dq + off + 16 * dt) = z;
+        *(f4*)(IO.dqa + off + 16 * dt) = oqa[dt];
+      }
+      if (full && IO.dgate_logits && !IO.dgate_summed)
+        for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, 16 * t + 4 * g, L, true, z);
+    }
+    return;
+  }
+#endif
   float wko[KS], wkd[KS];
 #pragma unroll
   for (int s4 = 0; s4 < KS / 4; ++s4) {
@@ -417,9 +533,6 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
       wkd[4 * s4 + e] = dk[e];
     }
   }
-  const int i0 = 16 * qb;
-  const bool rows_see_a_key = causal ? F.first_valid <= i0 : F.any_valid;
-  const int nt = rows_see_a_key ? min(causal ? min(nT, qb + 1) : nT, F.nt_valid) : nT;
   const bool order_select = !causal || __ballot(R.dead) != 0ull;
   const float* grow = P.gate_logits + (rowbase + (R.row_ok ? R.i : 0)) * L;
   const float* dmrow = IO.d_attack_mask ? IO.d_attack_mask + prow : nullptr;
@@ -599,6 +712,39 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     const int nt_q = rows_see_a_key ? min(causal ? min(nT, qb + 1) : nT, F.nt_valid) : nT;
     if (t >= nt_q) continue;  // the row kernel skipped this pair too: it carries no probability mass
     if (!qblock_active(IO, b, qb)) continue;
+#ifndef ACATTN_BWD_NO_MASK_ONLY
+    if (!qblock_has_ctx(IO, b, qb)) {  // [r4] mask-only pair (mask_tile): d Sa alone, into dKa
+      MaskRow<DH> R;
+      load_mask_row<DH>(P, IO, F, rowbase, bh, hoff, qb, c, g, R);
+      const float sM = ws[(bh * L + (R.row_ok ? R.i : 0)) * NSC + 4];
+      const uint32_t prow = prow_base + (uint32_t)(R.row_ok ? R.i : 0) * (uint32_t)L;
+      const int j0 = 16 * t + 4 * g;
+      f4 aM = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < KS / 4; ++s4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aM = mfma16(ka4[s4][e], R.qaf[4 * s4 + e], aM);
+      uint32_t eb4, ab4;
+      tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
+      const f4 dMext = IO.d_attack_mask ? load_seg(IO.d_attack_mask + prow, j0, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
+      const float dpen2 = IO.d_penalty_part ? 2.0f * IO.d_penalty_part[(size_t)bh * nT + qb] : 0.f;
+      f4 Mt, dM;
+      mask_tile(R, K, aM, t, g, eb4, dMext, dpen2, Mt, dM);
+      const f4 dSa = (Mt * (dM - sM)) * K.inv_sqrt;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      *(f4*)(&tr[1][c * TS + 4 * g]) = dSa;
+      float qac[4][DT];
+      col_frag<DH>(P.qa, rowbase, H, hoff, i0, L, c, g, qac);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float b_sa = tr[1][(4 * g + s) * TS + c];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) aKa[dt] = mfma16(qac[s][dt], b_sa, aKa[dt]);
+      }
+      continue;
+    }
+#endif
     Row<DH> R;
     load_row<DH>(P, IO, F, rowbase, bh, hoff, qb, c, g, R);
     const bool order_select = !causal || __ballot(R.dead) != 0ull;
@@ -783,23 +929,56 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
   const float lead = slice == 0 ? 1.0f : 0.0f;
   const int t = kgrp >> 2, g = kgrp & 3, j0 = 4 * kgrp;
   f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS, aP = aS, aW = aS, co4 = aS, cd4 = aS;
+  if constexpr (SLICED) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const size_t o = (rowbase + min(j0 + r, L - 1)) * H + hoff;
+    for (int r = 0; r < 4; ++r) {
+      const size_t o = (rowbase + min(j0 + r, L - 1)) * H + hoff;
 #pragma unroll
-    for (int k4 = 0; k4 < N4; ++k4) {  // (compile-time trip count: every load of the lane is in flight at once)
-      const int d4 = d_lo + k4;
-      const f4 kv = *(const f4*)(P.k + o + 4 * d4), kav = *(const f4*)(P.ka + o + 4 * d4), vv = *(const f4*)(P.v + o + 4 * d4);
-      const f4 q4 = *(const f4*)(&vec[0][4 * d4]), qa4 = *(const f4*)(&vec[1][4 * d4]);
-      const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
-      const f4 wo4 = *(const f4*)(&vec[4][4 * d4]), wd4 = *(const f4*)(&vec[5][4 * d4]);
-      aS[r] += hsum(kv * q4);
-      aM[r] += hsum(kav * qa4);
-      aP[r] += hsum(vv * ga4);
-      aW[r] += hsum(vv * gc4);
-      co4[r] += hsum(kv * wo4);
-      cd4[r] += hsum(kv * wd4);
+      for (int k4 = 0; k4 < N4; ++k4) {  // (compile-time trip count: every load of the lane is in flight at once)
+        const int d4 = d_lo + k4;
+        const f4 kv = *(const f4*)(P.k + o + 4 * d4), kav = *(const f4*)(P.ka + o + 4 * d4), vv = *(const f4*)(P.v + o + 4 * d4);
+        const f4 q4 = *(const f4*)(&vec[0][4 * d4]), qa4 = *(const f4*)(&vec[1][4 * d4]);
+        const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
+        const f4 wo4 = *(const f4*)(&vec[4][4 * d4]), wd4 = *(const f4*)(&vec[5][4 * d4]);
+        aS[r] += hsum(kv * q4);
+        aM[r] += hsum(kav * qa4);
+        aP[r] += hsum(vv * ga4);
+        aW[r] += hsum(vv * gc4);
+        co4[r] += hsum(kv * wo4);
+        cd4[r] += hsum(kv * wd4);
+      }
     }
+  } else {
+    // [r4] long rows (one key group per lane, the whole head dimension): column piece by column piece -- the row's six
+    // vectors are read from LDS once per piece, the 12 row pieces of the lane's 4 keys are in flight together, and the fence
+    // keeps the scheduler from hoisting every piece's loads to the top (that form needed 512 registers + 277 spilled and
+    // 1.2 KB of scratch per lane at head size 32: 166 us per launch at B = 512, L = 200)
+    size_t o4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] = (rowbase + min(j0 + r, L - 1)) * H + hoff;
+#pragma unroll 2
+    for (int k4 = 0; k4 < N4; ++k4) {  // a real loop: two pieces (24 row loads) in flight per trip
+      const f4 q4 = *(const f4*)(&vec[0][4 * k4]), qa4 = *(const f4*)(&vec[1][4 * k4]);
+      const f4 ga4 = *(const f4*)(&vec[2][4 * k4]), gc4 = *(const f4*)(&vec[3][4 * k4]);
+      const f4 wo4 = *(const f4*)(&vec[4][4 * k4]), wd4 = *(const f4*)(&vec[5][4 * k4]);
+      f4 kv[4], kav[4], vv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        kv[r] = *(const f4*)(P.k + o4[r] + 4 * k4);
+        kav[r] = *(const f4*)(P.ka + o4[r] + 4 * k4);
+        vv[r] = *(const f4*)(P.v + o4[r] + 4 * k4);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        aS[r] += hsum(kv[r] * q4);
+        aM[r] += hsum(kav[r] * qa4);
+        aP[r] += hsum(vv[r] * ga4);
+        aW[r] += hsum(vv[r] * gc4);
+        co4[r] += hsum(kv[r] * wo4);
+        cd4[r] += hsum(kv[r] * wd4);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (sliced) {
 #pragma unroll
@@ -845,28 +1024,59 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
   }
 
   // ---- key side: dk, dka, dv of the lane's 4 keys (rank one in the row's vectors) ------------------------------------------
+  if constexpr (SLICED) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int j = j0 + r;
-    if (j < L) {
-      const size_t o = (rowbase + j) * H + hoff;
+    for (int r = 0; r < 4; ++r) {
+      const int j = j0 + r;
+      if (j < L) {
+        const size_t o = (rowbase + j) * H + hoff;
 #pragma unroll
-      for (int k4 = 0; k4 < N4; ++k4) {
-        const int d4 = d_lo + k4;
-        const f4 q4 = *(const f4*)(&vec[0][4 * d4]), qa4 = *(const f4*)(&vec[1][4 * d4]);
-        const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
-        const f4 wo_hi = *(const f4*)(P.w_order + DH + 4 * d4), wd_hi = *(const f4*)(P.w_dist + DH + 4 * d4);
-        *(f4*)(IO.dk + o + 4 * d4) = q4 * dS[r] + wo_hi * d_o[r] + wd_hi * d_d[r];
-        if (ACC)
-          *(f4*)(IO.dka + o + 4 * d4) += qa4 * dSa[r];
-        else
-          *(f4*)(IO.dka + o + 4 * d4) = qa4 * dSa[r];
-        *(f4*)(IO.dv + o + 4 * d4) = ga4 * T.Ap[r] + gc4 * T.Aw[r];
+        for (int k4 = 0; k4 < N4; ++k4) {
+          const int d4 = d_lo + k4;
+          const f4 q4 = *(const f4*)(&vec[0][4 * d4]), qa4 = *(const f4*)(&vec[1][4 * d4]);
+          const f4 ga4 = *(const f4*)(&vec[2][4 * d4]), gc4 = *(const f4*)(&vec[3][4 * d4]);
+          const f4 wo_hi = *(const f4*)(P.w_order + DH + 4 * d4), wd_hi = *(const f4*)(P.w_dist + DH + 4 * d4);
+          *(f4*)(IO.dk + o + 4 * d4) = q4 * dS[r] + wo_hi * d_o[r] + wd_hi * d_d[r];
+          if (ACC)
+            *(f4*)(IO.dka + o + 4 * d4) += qa4 * dSa[r];
+          else
+            *(f4*)(IO.dka + o + 4 * d4) = qa4 * dSa[r];
+          *(f4*)(IO.dv + o + 4 * d4) = ga4 * T.Ap[r] + gc4 * T.Aw[r];
+        }
       }
     }
+  } else {  // [r4] column piece by column piece, as above
+#pragma unroll 2
+    for (int k4 = 0; k4 < N4; ++k4) {
+      const f4 q4 = *(const f4*)(&vec[0][4 * k4]), qa4 = *(const f4*)(&vec[1][4 * k4]);
+      const f4 ga4 = *(const f4*)(&vec[2][4 * k4]), gc4 = *(const f4*)(&vec[3][4 * k4]);
+      const f4 wo_hi = *(const f4*)(P.w_order + DH + 4 * k4), wd_hi = *(const f4*)(P.w_dist + DH + 4 * k4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + r;
+        if (j < L) {
+          const size_t o = (rowbase + j) * H + hoff;
+          *(f4*)(IO.dk + o + 4 * k4) = q4 * dS[r] + wo_hi * d_o[r] + wd_hi * d_d[r];
+          if (ACC)
+            *(f4*)(IO.dka + o + 4 * k4) += qa4 * dSa[r];
+          else
+            *(f4*)(IO.dka + o + 4 * k4) = qa4 * dSa[r];
+          *(f4*)(IO.dv + o + 4 * k4) = ga4 * T.Ap[r] + gc4 * T.Aw[r];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- gate-logit gradient: the read row carries dgl, every other row is zero --------------------------------------------------
-  if (IO.dgate_logits) {
+  if (IO.dgate_logits && IO.dgate_summed) {
+    // [r4] head-summed form ([B,L,L], zeroed by the launcher): this head's read row is ADDED, nothing else is touched
+    if (slice == 0) {
+      float* grow = IO.dgate_logits + ((size_t)b * L + i) * L;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (j0 + r < L) atomicAdd(grow + j0 + r, dgl[r]);
+    }
+  } else if (IO.dgate_logits) {
     float* gbase = IO.dgate_logits + bh * (size_t)L * L;
     for (int row = 0; row < L; ++row) {
       if (row == i) continue;
@@ -937,6 +1147,10 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
 template <int DH>
 int launch_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream) {
   const dim3 grid(p.B * p.n_heads), block(64);
+  if (io.dgate_logits && io.dgate_summed) {  // the heads add their read row into a zeroed [B,L,L]
+    const int rc = acattn_launch_zero(io.dgate_logits, (size_t)p.B * p.L * p.L, stream);
+    if (rc) return rc;
+  }
   if (p.L <= 64) {
     if (accumulate)
       hipLaunchKernelGGL((acattn_bwd_onerow_kernel<DH, true, true>), grid, block, 0, stream, p, io);
@@ -982,13 +1196,17 @@ int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p) { return (int64_t)p.
 // The calibrated-loss pass through the LAST layer: only the read position of every sequence carries a cotangent
 // (io.read_rows with one position per sequence, no mask cotangent).  Returns -100 when that is not the situation.
 // `accumulate`: see the kernel (the caller has run the mask path; io.d_attack_mask must then be NULL here).
-int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream) {
+bool acattn_bwd_onerow_applies(const acattn_problem& p, const acattn_bwd_io& io) {
   static const bool enabled = getenv("ACATTN_ONEROW") ? atoi(getenv("ACATTN_ONEROW")) != 0 : true;
-  const bool ok = enabled && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.d_attack_mask && !io.d_penalty_part && !io.attack_only &&
-                  p.L <= 208 && (int64_t)p.B * p.n_heads * p.L * p.L < (1LL << 30) && (int64_t)p.B * p.L * p.H < (1LL << 30) &&
-                  p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order && p.w_dist &&
-                  p.adversarial && p.combine_option == ACATTN_COMBINE_GATE && p.two_level;
-  if (!ok) return -100;
+  const int dh = p.n_heads > 0 ? p.H / p.n_heads : 0;
+  return enabled && io.read_rows && io.n_read_rows == 1 && !io.active_qblocks && !io.d_attack_mask && !io.d_penalty_part && !io.attack_only &&
+         p.L <= 208 && (int64_t)p.B * p.n_heads * p.L * p.L < (1LL << 30) && (int64_t)p.B * p.L * p.H < (1LL << 30) &&
+         p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order && p.w_dist &&
+         p.adversarial && p.combine_option == ACATTN_COMBINE_GATE && p.two_level && (dh == 16 || dh == 32 || dh == 64 || dh == 128);
+}
+
+int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, bool accumulate, hipStream_t stream) {
+  if (!acattn_bwd_onerow_applies(p, io)) return -100;
   switch (p.H / p.n_heads) {
     case 16: return launch_onerow<16>(p, io, accumulate, stream);
     case 32: return launch_onerow<32>(p, io, accumulate, stream);

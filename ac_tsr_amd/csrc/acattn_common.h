@@ -236,6 +236,18 @@ __device__ __forceinline__ RngDraw rng_draw_half(const RngKey key, uint32_t row_
   return o;
 }
 
+// The keep decisions of the attack mask's dropout alone (keep_mask of rng_group / rng_draw_half for the same arguments):
+// the streaming forward needs them before it needs the normals (M leaves early, acattn_fwd_stream.inc pass 1.5).
+__device__ __forceinline__ uint32_t rng_keep_mask_half(const RngKey key, uint32_t row_id, uint32_t grp) {
+  uint32_t x = (row_id * 64u + grp) ^ key.a;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  x += key.b;
+  return (rng_word(x, 0xB5297A4Du, 0x85EBCA77u) >> 12) & 0xFu;
+}
+
 // keep bits -> what dropout multiplies by
 __device__ __forceinline__ f4 keep_scale4(uint32_t bits, float keep_scale) {
   f4 s;
@@ -310,6 +322,7 @@ int acattn_fwd_kernel_choice(int which);
 int acattn_bwd_kernel_choice(int which);
 int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p);
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
+bool acattn_bwd_gate_summed(const acattn_problem& p, const acattn_bwd_io& io);  // acattn_bwd_io.dgate_summed (acattn_bwd.hip)
 int acattn_launch_spatial_affines(const acattn_problem& p, float* affine, hipStream_t stream);
 int acattn_launch_rng(int B, int nh, int L, uint64_t seed, float p_drop, float* noise, uint8_t* keep_after,
                       uint8_t* keep_mask, uint8_t* keep_before, hipStream_t stream);

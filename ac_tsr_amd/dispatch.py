@@ -174,8 +174,7 @@ def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
     io.d_ctx_attacked, io.d_ctx_calibrated, io.d_attack_mask = _ptr(d_ctx_attacked), _ptr(d_ctx_calibrated), _ptr(d_attack_mask)
     dq, dk, dv, dqa, dka = (torch.empty_like(q) for _ in range(5))
     io.dq, io.dk, io.dv, io.dqa, io.dka = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqa), _ptr(dka)
-    dgate_part = torch.empty(B, n_heads, L, L, device=q.device, dtype=torch.float32)
-    io.dgate_logits = _ptr(dgate_part)
+    io.dgate_logits = _ptr(q)  # (placeholder for the query below: only tested for NULL)
     # the three per-(b, head) partial sums share ONE [B*nh, 4*dh + 4] buffer, reduced in a single pass by the caller
     width = 4 * dh + 4
     part = torch.empty(B * n_heads, width, device=q.device, dtype=torch.float32)
@@ -190,6 +189,11 @@ def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
         io.read_rows, io.n_read_rows = _ptr(read_rows), read_rows.shape[1]
     io.attack_only = int(attack_only)
     io.d_penalty_part = _ptr(d_penalty_part)  # [B, n_heads, ceil(L/16)]: include/acattn.h
+    # one read position per sequence: ONE row of each sequence's gate gradient is non-zero, and the one-row form of the
+    # backward adds it straight into the head-summed [B,L,L] tensor (acattn_bwd_io.dgate_summed); returned as [B,1,L,L]
+    summed = bool(lib.acattn_calibrated_attention_bwd_gate_summed(C.byref(prob), C.byref(io)))
+    dgate_part = torch.empty(B, 1 if summed else n_heads, L, L, device=q.device, dtype=torch.float32)
+    io.dgate_logits, io.dgate_summed = _ptr(dgate_part), int(summed)
     _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
     return dq, dk, dv, dqa, dka, dgate_part, part
 
@@ -200,7 +204,12 @@ def _bwd_meta(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
     B, L, H = q.shape
     dh = H // n_heads
     e = lambda: torch.empty_like(q)
-    return e(), e(), e(), e(), e(), q.new_empty(B, n_heads, L, L), q.new_empty(B * n_heads, 4 * dh + 4)
+    # (the one-row form returns the gate gradient already summed over the heads: same rule as the library's query for the
+    # dispatcher form -- one read position, no block bitmap, no mask cotangent or L <= 64 for the split, not attack-only)
+    one = (read_rows is not None and read_rows.shape[1] == 1 and active_qblocks is None and not attack_only and L <= 208
+           and dh in (16, 32, 64, 128)
+           and ((d_attack_mask is None and d_penalty_part is None) or (L <= 64 and dh <= 64)))
+    return e(), e(), e(), e(), e(), q.new_empty(B, 1 if one else n_heads, L, L), q.new_empty(B * n_heads, 4 * dh + 4)
 
 
 _LIB.impl("calibrated_attention_fwd", _fwd_cuda, "CUDA")
@@ -237,7 +246,7 @@ def _backward(ctx, d_att, d_cal, d_M, _d_stats, d_pen=None):
     dh = q.shape[-1] // n_heads
     tot = part.sum(0)
     small = tot[4 * dh:]
-    return (dq, dk, dv, dqa, dka, dgate_part.sum(1), None, None, tot[:2 * dh].view_as(w_order), small[0:1].view_as(b_order),
+    return (dq, dk, dv, dqa, dka, (dgate_part[:, 0] if dgate_part.shape[1] == 1 else dgate_part.sum(1)), None, None, tot[:2 * dh].view_as(w_order), small[0:1].view_as(b_order),
             tot[2 * dh:4 * dh].view_as(w_dist), small[1:2].view_as(b_dist), small[2:3].view_as(scalar), None, None, None, None,
             None, None, None, None)
 

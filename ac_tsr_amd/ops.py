@@ -300,8 +300,7 @@ class _CalibratedAttention(torch.autograd.Function):
         io.dq, io.dk, io.dv, io.dqa, io.dka = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqa), _ptr(dka)
         dgate = dgate_part = None
         if cfg.combine_option == "gate":
-            dgate_part = torch.empty(B, nh, L, L, device=q.device, dtype=torch.float32)
-            io.dgate_logits = _ptr(dgate_part)
+            io.dgate_logits = _ptr(q)  # (placeholder for the query below: only tested for NULL)
         # the three per-(b, head) partial sums share ONE [B*nh, 4*dh + 4] buffer, reduced in a single pass
         width = 4 * dh + 4
         part = torch.empty(B * nh, width, device=q.device, dtype=torch.float32)
@@ -319,6 +318,10 @@ class _CalibratedAttention(torch.autograd.Function):
         # pass 2 through a layer with nothing attack-related upstream: only the attack transforms' inputs matter
         attack_only = ctx.state.attack_pass_only and not ctx.attack_upstream
         io.attack_only = int(attack_only)
+        if cfg.combine_option == "gate":
+            summed = bool(lib.acattn_calibrated_attention_bwd_gate_summed(C.byref(prob), C.byref(io)))  # see dispatch._bwd_cuda
+            dgate_part = torch.empty(B, 1 if summed else nh, L, L, device=q.device, dtype=torch.float32)
+            io.dgate_logits, io.dgate_summed = _ptr(dgate_part), int(summed)
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
         return _CalibratedAttention._finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh, w_order,
                                                      b_order, w_dist, b_dist, scalar, rich_ratio)
@@ -340,8 +343,8 @@ class _CalibratedAttention(torch.autograd.Function):
                                                 _ptr(part), _ptr(tot), 1, part.shape[0], part.shape[1], _stream()),
                        "sum_rows_pair")
         else:
-            if dgate_part is not None:
-                dgate = sum_rows(dgate_part, 1)
+            if dgate_part is not None:  # (one head, or the one-row form's head-summed tensor: nothing to add)
+                dgate = dgate_part[:, 0] if dgate_part.shape[1] == 1 else sum_rows(dgate_part, 1)
             tot = sum_rows(part, 0)
         small = tot[4 * dh:]
         g_wo = tot[:2 * dh].view_as(w_order) if w_order is not None else None

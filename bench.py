@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--dp-collective", choices=["all_reduce", "reduce_scatter"], default="all_reduce",
                     help="gradient exchange under data parallelism: one all-reduce per bucket, or reduce-scatter + "
                          "all-gather (parallel.GradSynchronizer)")
+    ap.add_argument("--combined-backward", action="store_true",
+                    help="opt-in trainer mode: ONE backward walk carries the cotangents of both losses (ac_tsr_amd/combined.py) "
+                         "instead of the reference protocol's two walks; same gradients")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffer, graph without optimizer) even on one GPU")
     a = ap.parse_args()
@@ -423,7 +426,8 @@ def main():
         model.cloze_on_device = True  # the cloze batch is built with tensor ops: the whole step replays as a graph
     parallel.broadcast_parameters(model)
     sync = parallel.GradSynchronizer.for_two_pass_model(model, collective=a.dp_collective) if (world > 1 or a.force_grad_sync) else None
-    trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model, grad_sync=sync)
+    trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model, grad_sync=sync,
+                                    combined_backward=a.combined_backward)
     model.train()
     gen = torch.Generator().manual_seed(1000 + rank)
     pool = [synthetic_batch(a.batch, a.seq_len, a.items, gen, device) for _ in range(8)]
@@ -499,6 +503,7 @@ def main():
                              f"h={a.heads} {a.layers} layers inner={a.inner}, CE loss, two-pass backward + Adam"),
                 "global_batch": world * a.batch, "seq_len": a.seq_len, "hidden": a.hidden, "heads": a.heads,
                 "parallelism": f"dp{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if rehearsal else ""), "launch": "eager" if a.no_graph else "hipGraph replay per step",
+                "backward": "one combined walk (opt-in)" if a.combined_backward else "two walks (reference protocol, trainer.py:672-686)",
                 "final_losses": [round(att, 4), round(cal, 4)],
                 "reference_schedule": None if full_ms is None else {
                     "ms_per_step": round(full_ms, 3), "value": round(a.batch / full_ms * 1e3, 1),

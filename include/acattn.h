@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 26
+#define ACATTN_ABI_VERSION 27
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -164,6 +164,13 @@ typedef struct acattn_bwd_io {
                            kernels then add d M = 2 * d_penalty_part[b, head, query block] * (M - 1) to the mask cotangent
                            from the M tile they rebuild -- the mask penalty's gradient (acsasrec.py:131-137) without a
                            dense [B,nh,L,L] cotangent.  Like d_attack_mask it keeps every query block active. */
+  int32_t dgate_summed; /* ABI 27, request: `dgate_logits` is [B,L,L] and receives the gate-logit gradient SUMMED over the heads
+                           (the gate is shared by them, layers.py:887 unsqueeze(1)) instead of [B,nh,L,L] per-head partials.
+                           Honoured by the one-row form of the backward only (one read position per sequence,
+                           acattn_bwd_io.read_rows with n_read_rows == 1: of each sequence's L x L gate gradient ONE row is
+                           non-zero, and writing nh dense partials of it -- 164 MB of zeros at B = 512, L = 200, 2 heads --
+                           plus summing them was most of that launch): ask acattn_calibrated_attention_bwd_gate_summed()
+                           first; a launch that cannot honour the request fails instead of misreading the buffer. */
 } acattn_bwd_io;
 
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
@@ -468,6 +475,11 @@ typedef struct acattn_adam_group {
 } acattn_adam_group;
 int acattn_adam_step(const acattn_adam_group* g, double lr, double beta1, double beta2, double eps, double weight_decay,
                      int32_t* done, void* stream);
+
+/* ABI 27: 1 when acattn_calibrated_attention_bwd(p, io) with io->dgate_summed = 1 will write the head-summed [B,L,L] gate
+ * gradient (see acattn_bwd_io.dgate_summed), 0 when the launch needs the per-head [B,nh,L,L] buffer.  Validates nothing
+ * else; every other field of `io` as for the launch itself (pointers are only tested for NULL). */
+int acattn_calibrated_attention_bwd_gate_summed(const acattn_problem* p, const acattn_bwd_io* io);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);
