@@ -471,24 +471,36 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     // of the context chain are zero; no parameter partials ---------------------------------------------------------------------
     const float* dmrow_m = IO.d_attack_mask ? IO.d_attack_mask + prow : nullptr;
     const float dpen2_m = IO.d_penalty_part ? 2.0f * IO.d_penalty_part[(size_t)bh * nT + qb] : 0.f;
-    auto tile = [&](int t, f4& Mt, f4& dM) {
-      f4 ka4[DT];
-      row_frag<DH>(P.ka, rowbase, H, hoff, 16 * t, L, c, g, ka4);
-      f4 aM = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s4 = 0; s4 < KS / 4; ++s4)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) aM = mfma16(ka4[s4][e], R.qaf[4 * s4 + e], aM);
-      uint32_t eb4, ab4;
-      tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
-      const f4 dMext = dmrow_m ? load_seg(dmrow_m, 16 * t + 4 * g, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f};
-      mask_tile(R, K, aM, t, g, eb4, dMext, dpen2_m, Mt, dM);
-    };
+    // Each tile is one product, four exponentials and a few dozen other instructions: what a wave of this path spends its
+    // life on is waiting for the tile's Ka rows.  So the tiles are unrolled (13 = ceil(208 / 16)), the rows of tile t + 1
+    // are requested before tile t is worked on (two register sets, roles fixed per tile), and Mt / d M of every tile stay in
+    // registers (104 of them: this path has the room), so sweep 2 is the dqa product alone, its Ka columns prefetched alike.
+    constexpr int NTM = 13;
+    f4 Mt[NTM], dMk[NTM];
+    f4 ka_a[DT], ka_b[DT], dme_a = {0.f, 0.f, 0.f, 0.f}, dme_b = dme_a;
+    row_frag<DH>(P.ka, rowbase, H, hoff, 0, L, c, g, ka_a);
+    if (dmrow_m) dme_a = load_seg(dmrow_m, 4 * g, L, R.row_ok);
     float s_m = 0.f;
-    for (int t = 0; t < nt; ++t) {
-      f4 Mt, dM;
-      tile(t, Mt, dM);
-      s_m += hsum(Mt * dM);
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+      if (t < nt) {
+        f4(&cur)[DT] = (t & 1) ? ka_b : ka_a;
+        f4(&nxt)[DT] = (t & 1) ? ka_a : ka_b;
+        const f4 dcur = (t & 1) ? dme_b : dme_a;
+        if (t + 1 < nt) {
+          row_frag<DH>(P.ka, rowbase, H, hoff, 16 * (t + 1), L, c, g, nxt);
+          if (dmrow_m) ((t & 1) ? dme_a : dme_b) = load_seg(dmrow_m, 16 * (t + 1) + 4 * g, L, R.row_ok);
+        }
+        f4 aM = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < KS / 4; ++s4)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) aM = mfma16(cur[s4][e], R.qaf[4 * s4 + e], aM);
+        uint32_t eb4, ab4;
+        tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
+        mask_tile(R, K, aM, t, g, eb4, dcur, dpen2_m, Mt[t], dMk[t]);
+        s_m += hsum(Mt[t] * dMk[t]);
+      }
     }
     const float sM = quad_sum(s_m);
     if (R.row_ok && g == 0) {
@@ -498,16 +510,20 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     f4 oqa[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oqa[dt] = f4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nt; ++t) {
-      f4 Mt, dM;
-      tile(t, Mt, dM);
-      const f4 dSa = (Mt * (dM - sM)) * K.inv_sqrt;
-      float kac[4][DT];
-      col_frag<DH>(P.ka, rowbase, H, hoff, 16 * t, L, c, g, kac);
+    float kc_a[4][DT], kc_b[4][DT];
+    col_frag<DH>(P.ka, rowbase, H, hoff, 0, L, c, g, kc_a);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+    for (int t = 0; t < NTM; ++t) {
+      if (t < nt) {
+        float(&cur)[4][DT] = (t & 1) ? kc_b : kc_a;
+        float(&nxt)[4][DT] = (t & 1) ? kc_a : kc_b;
+        if (t + 1 < nt) col_frag<DH>(P.ka, rowbase, H, hoff, 16 * (t + 1), L, c, g, nxt);
+        const f4 dSa = (Mt[t] * (dMk[t] - sM)) * K.inv_sqrt;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) oqa[dt] = mfma16(kac[r][dt], dSa[r], oqa[dt]);
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) oqa[dt] = mfma16(cur[r][dt], dSa[r], oqa[dt]);
+      }
     }
     if (R.row_ok) {
       const f4 z = {0.f, 0.f, 0.f, 0.f};
@@ -716,6 +732,8 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     if (!qblock_has_ctx(IO, b, qb)) {  // [r4] mask-only pair (mask_tile): d Sa alone, into dKa
       MaskRow<DH> R;
       load_mask_row<DH>(P, IO, F, rowbase, bh, hoff, qb, c, g, R);
+      float qac[4][DT];  // every load of the pair is requested here, in front of the first wait: one round trip per pair
+      col_frag<DH>(P.qa, rowbase, H, hoff, i0, L, c, g, qac);
       const float sM = ws[(bh * L + (R.row_ok ? R.i : 0)) * NSC + 4];
       const uint32_t prow = prow_base + (uint32_t)(R.row_ok ? R.i : 0) * (uint32_t)L;
       const int j0 = 16 * t + 4 * g;
@@ -733,8 +751,6 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
       const f4 dSa = (Mt * (dM - sM)) * K.inv_sqrt;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       *(f4*)(&tr[1][c * TS + 4 * g]) = dSa;
-      float qac[4][DT];
-      col_frag<DH>(P.qa, rowbase, H, hoff, i0, L, c, g, qac);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
