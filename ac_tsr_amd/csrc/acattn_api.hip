@@ -289,6 +289,19 @@ int acattn_layer_tail_bwd(const acattn_tail_problem* p, const acattn_tail_saved*
   return rc;
 }
 
+int acattn_step_inputs(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n_copies, int64_t* counter,
+                       const int64_t* item_length, int64_t* last_row, int32_t n_rows, void* stream) {
+  if (n_copies < 0 || n_copies > ACATTN_MAX_COPIES) return fail("step inputs: 0 .. ACATTN_MAX_COPIES copies");
+  if (n_copies > 0 && (!src || !dst || !bytes)) return fail("step inputs: src, dst, bytes must be non-NULL");
+  for (int k = 0; k < n_copies; ++k)
+    if (bytes[k] > 0 && (!src[k] || !dst[k])) return fail("step inputs: NULL copy operand");
+  if ((item_length == nullptr) != (last_row == nullptr)) return fail("step inputs: item_length and last_row come together");
+  if (last_row && n_rows < 1) return fail("step inputs: n_rows must be positive");
+  const int rc = acattn_launch_step_inputs(src, dst, bytes, n_copies, counter, item_length, last_row, n_rows, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_t C, void* stream) {
   if (!x || !out) return fail("x and out must be non-NULL");
   if (batch < 1 || R < 1 || C < 1) return fail("batch, R, C must be positive");

@@ -375,6 +375,8 @@ int acattn_launch_penalty_bwd(const float* m, const float* norm, const float* d_
                               hipStream_t stream);
 // zero fill by a kernel (acattn_util.hip: memset nodes inside a hipGraph proved unreliable for accumulate-into-zero buffers)
 int acattn_launch_zero(float* p, size_t n, hipStream_t stream);
+int acattn_launch_step_inputs(const void* const* src, void* const* dst, const int64_t* bytes, int n, int64_t* counter,
+                              const int64_t* item_length, int64_t* last_row, int n_rows, hipStream_t stream);
 int acattn_launch_penalty_partial_multi(const float* const* m, int n_masks, int64_t n, float* part, hipStream_t stream);
 int acattn_launch_penalty_bwd_scaled_multi(const float* const* m, const float* norms, const float* d_loss, float scale,
                                            int64_t n, float* const* d_m, int n_masks, hipStream_t stream);

@@ -180,7 +180,9 @@ class ACSASRec(SequentialRecommender):
         if isinstance(module, nn.Linear) and module.bias is not None:
             module.bias.data.zero_()
 
-    def forward(self, item_seq, item_seq_len, is_train=False, _rnds=None, _keep_emb=None):
+    def forward(self, item_seq, item_seq_len, is_train=False, _rnds=None, _keep_emb=None, _last_row=None):
+        """`_last_row` ([B] int64, optional): item_seq_len - 1 already on the device (the trainer's graph mode forms it in
+        the launch that copies the batch in: acattn_step_inputs)."""
         input_emb, mask = _front_end(self, item_seq, _keep_emb, self.bidirectional)
         # only position item_seq_len - 1 of the last layer is read (acsasrec.py:100-103): the encoder is told, so the
         # last layer's position-wise tail runs on B rows instead of B * L (gather and tail commute)
@@ -189,7 +191,7 @@ class ACSASRec(SequentialRecommender):
             attacked_output, calibrated_output = trm_output[0][-1]
             return (self.gather_indexes(attacked_output, item_seq_len - 1),
                     self.gather_indexes(calibrated_output, item_seq_len - 1), trm_output[1])
-        last = (item_seq_len - 1).view(-1, 1)
+        last = (item_seq_len - 1).view(-1, 1) if _last_row is None else _last_row.view(-1, 1)
         trm_output = self.trm_encoder(input_emb, mask, output_all_encoded_layers=False, _rnds=_rnds, _last_rows=last)
         all_attack_masks = trm_output[1]
         attacked_output, calibrated_output = trm_output[0][-1]
@@ -213,8 +215,9 @@ class ACSASRec(SequentialRecommender):
     def calculate_loss(self, interaction, _rnds=None, _keep_emb=None):
         item_seq = interaction[self.ITEM_SEQ]
         item_seq_len = interaction[self.ITEM_SEQ_LEN]
+        last_row = interaction.get("_acattn_last_row") if isinstance(interaction, dict) else None
         attacked_output, calibrated_output, all_attack_masks = self.forward(item_seq, item_seq_len, is_train=True,
-                                                                            _rnds=_rnds, _keep_emb=_keep_emb)
+                                                                            _rnds=_rnds, _keep_emb=_keep_emb, _last_row=last_row)
         final_attacked_loss = None
         if attacked_output is not None:
             if (self.loss_type == 'CE' and not self.trainable_mask_loss_weight and attacked_output.is_cuda

@@ -93,7 +93,7 @@ class AttackSASRecTrainer:
 
     def _pass_one(self, interaction, check_nan: bool = False):
         """Forward + backward pass 1 of one batch (trainer.py:660-677).  Returns the two losses."""
-        if self._seed_t is not None:
+        if self._seed_t is not None and not self._fused_inputs:
             self._seed_t += 1  # fresh in-kernel randomness on every (replayed) step
         if self.grad_sync is not None:
             self.grad_sync.zero_grad()
@@ -111,17 +111,17 @@ class AttackSASRecTrainer:
         # `backward(inputs=...)` accumulates into exactly the same leaves with the same values, and lets
         # autograd skip the branches that only feed frozen leaves (weight-gradient GEMMs, embedding scatter).
         with self.state.calibrated_pass():
-            calibrated_loss.backward(retain_graph=attacked_loss is not None, inputs=self._others)
+            calibrated_loss.backward(self._root(calibrated_loss), retain_graph=attacked_loss is not None, inputs=self._others)
         return attacked_loss, calibrated_loss
 
     def _pass_two(self, attacked_loss):
         """Backward pass 2 (trainer.py:678-684): only the attack transforms accumulate."""
         if attacked_loss is not None:
             with self.state.attack_pass():
-                attacked_loss.backward(inputs=self._attack)
+                attacked_loss.backward(self._root(attacked_loss), inputs=self._attack)
 
     def _forward(self, interaction, check_nan: bool = False):
-        if self._seed_t is not None:
+        if self._seed_t is not None and not self._fused_inputs:
             self._seed_t += 1
         if self.grad_sync is not None:
             self.grad_sync.zero_grad()
@@ -153,7 +153,7 @@ class AttackSASRecTrainer:
             self.state.combined = walk
             try:
                 walk.prefix(attacked_loss, calibrated_loss)
-                calibrated_loss.backward(inputs=self._others)
+                calibrated_loss.backward(self._root(calibrated_loss), inputs=self._others)
                 walk.finish()
             finally:
                 self.state.combined = None
@@ -181,6 +181,35 @@ class AttackSASRecTrainer:
         return attacked_loss, calibrated_loss
 
     _seed_t = None
+    _fused_inputs = False  # graph mode: the replay counter and the batch copies are ONE launch in front of the replay
+    _one = None            # the root cotangent of both backward walks (a constant: no fill launch per walk)
+
+    def _root(self, loss):
+        if self._one is None or self._one.device != loss.device:
+            self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+        return self._one
+
+    def _stage_inputs(self, interaction) -> bool:
+        """Graph mode: the batch into the static buffers, the replay counter + 1 and the read positions
+        (item_length - 1) in one launch (acattn_step_inputs).  False = this batch cannot go that way (the caller copies)."""
+        import ctypes as C
+        from . import _lib
+        keys = [k for k in self._static_in if not k.startswith("_acattn_")]
+        if len(keys) > 6 or any(not (interaction[k].is_cuda and interaction[k].is_contiguous() and interaction[k].dtype == self._static_in[k].dtype)
+                                for k in keys):
+            return False
+        n = len(keys)
+        src = (C.c_void_p * n)(*(interaction[k].data_ptr() for k in keys))
+        dst = (C.c_void_p * n)(*(self._static_in[k].data_ptr() for k in keys))
+        nbytes = (C.c_int64 * n)(*(self._static_in[k].numel() * self._static_in[k].element_size() for k in keys))
+        last = self._static_in.get("_acattn_last_row")
+        length = interaction[self.model.ITEM_SEQ_LEN] if last is not None else None
+        _lib.check(_lib.load().acattn_step_inputs(src, dst, nbytes, n, C.c_void_p(self._seed_t.data_ptr()),
+                                                  None if length is None else C.c_void_p(length.data_ptr()),
+                                                  None if length is None else C.c_void_p(last.data_ptr()),
+                                                  0 if length is None else length.numel(),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "step_inputs")
+        return True
 
     def enable_graph(self, example_interaction, warmup: int = 3, debug_dump: Optional[str] = None):
         """Capture the training step into hipGraphs (about 350 short kernels per step: eager launches are host-bound).
@@ -208,11 +237,19 @@ class AttackSASRecTrainer:
         self._static_in = {k: v.clone() for k, v in example_interaction.items()}
         self._seed_t = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.state.seed_tensor = self._seed_t
+        len_key = getattr(self.model, "ITEM_SEQ_LEN", None)
+        if (len_key in self._static_in and self._static_in[len_key].dtype == torch.int64
+                and type(self.model).__name__ == "ACSASRec" and all(v.is_cuda for v in self._static_in.values())):
+            # the position the model reads (item_length - 1, abstract_recommender.py:130-134), formed by the input launch
+            self._static_in["_acattn_last_row"] = self._static_in[len_key] - 1
+        self._fused_inputs = all(v.is_cuda and v.is_contiguous() for v in self._static_in.values()) and len(self._static_in) <= 6
         self.model.train()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
+                if self._fused_inputs:
+                    self._seed_t += 1
                 self._eager_step(self._static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -260,13 +297,22 @@ class AttackSASRecTrainer:
         to synchronise).  In graph mode the returned tensors are static buffers overwritten by the next step."""
         if self._graph is None:
             return self._eager_step(interaction, check_nan)
-        if any(interaction[k].shape != buf.shape for k, buf in self._static_in.items()):
+        if any(interaction[k].shape != buf.shape for k, buf in self._static_in.items() if not k.startswith("_acattn_")):
             # e.g. the shorter last batch of an epoch: the captured graph is shape-specific, run this one eagerly
+            if self._fused_inputs:
+                self._seed_t += 1  # (the eager step does not advance the replay counter itself in this mode)
             return self._eager_step(interaction, check_nan)
-        for k, buf in self._static_in.items():
-            src = interaction[k]
-            if src.data_ptr() != buf.data_ptr():
-                buf.copy_(src, non_blocking=True)
+        if not (self._fused_inputs and self._stage_inputs(interaction)):
+            for k, buf in self._static_in.items():
+                if k.startswith("_acattn_"):
+                    continue
+                src = interaction[k]
+                if src.data_ptr() != buf.data_ptr():
+                    buf.copy_(src, non_blocking=True)
+            if self._fused_inputs:  # (a batch the input launch cannot take: the pieces one by one)
+                self._seed_t += 1
+                if "_acattn_last_row" in self._static_in:
+                    torch.sub(self._static_in[self.model.ITEM_SEQ_LEN], 1, out=self._static_in["_acattn_last_row"])
         self._graph.replay()
         if self.grad_sync is not None:
             if self._graph2 is not None:

@@ -270,6 +270,16 @@ int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_
 int acattn_sum_rows_pair(const float* x1, float* out1, int32_t batch1, int32_t R1, int32_t C1, const float* x2, float* out2,
                          int32_t batch2, int32_t R2, int32_t C2, void* stream);
 
+/* ABI 27: the start of a (replayed) training step in ONE launch: up to ACATTN_MAX_COPIES device-to-device copies of the
+ * batch tensors into the static buffers a captured hipGraph reads (recbole/trainer/trainer.py:661 interaction.to(device)
+ * ends in such buffers here), `*counter += 1` when counter != NULL (the replay counter the in-kernel RNG adds to its
+ * seeds), and last_row[b] = item_length[b] - 1 when both are given (the position the models read,
+ * abstract_recommender.py:130-134; `item_length` is read from its SOURCE, so it may be one of the tensors being copied).
+ * Sizes in bytes, any alignment; src[i] == dst[i] is skipped. */
+#define ACATTN_MAX_COPIES 6
+int acattn_step_inputs(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n_copies, int64_t* counter,
+                       const int64_t* item_length, int64_t* last_row, int32_t n_rows, void* stream);
+
 /* The mask penalty || 1 - M ||_2 over a whole attack-mask tensor (torch.norm(1 - attack_mask, p=2):
  * recbole/model/sequential_recommender/acsasrec.py:131-137, acbert4rec.py:229-232) and its gradient
  * d_m = d_norm * (m - 1) / norm.  m has n floats (16-byte aligned); `workspace` holds
