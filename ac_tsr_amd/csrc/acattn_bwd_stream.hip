@@ -86,7 +86,11 @@ struct Tile {
 
 // Everything of tile_forward that follows the four products (raw scores S, Sa and the cotangents dA_p, dA_w of the
 // lane's 4 keys): RowT supplies the row's scalars (Row<DH>, or RowScalars of the one-row kernel).
-template <class RowT>
+// DCA = false [r4]: the launch has NO cotangent of the attacked context (every layer but the last: its attacked branch feeds
+// nothing, layers.py:1112).  Then d A_p = 0, so A_p itself, its argument and the Gaussian noise that only enters through it
+// (layers.py:917-919) are never needed: the Box-Muller draws -- a sixth of the tile's arithmetic -- fold away, one of the
+// four products (d A_p = d ctx_att . V^T) and its d V term go, and the row scalars da, the sums that carry it, vanish.
+template <class RowT, bool DCA = true>
 __device__ __forceinline__ void tile_elementwise(const RowT& R, const Consts& K, const f4 aS, const f4 aM, const f4 aP,
                                                  const f4 aW, const f4 co4, const f4 cd4, const f4 gl, const int t,
                                                  const int g, const uint32_t eb4, const uint32_t ab4,
@@ -129,13 +133,16 @@ __device__ __forceinline__ void tile_elementwise(const RowT& R, const Consts& K,
     T.P[r] = keep_and(T.P[r], T.ka, r);
     T.M[r] = keep_and(T.M[r], T.km, r);
   }
-  const f4 au = (T.P * T.M + T.nz * (1.0f - T.M)) * kLog2e - R.lu2;  // layers.py:918-919
   const f4 a1 = T.M * (-kLog2e) + kLog2e;
+  if constexpr (DCA) {
+    const f4 au = (T.P * T.M + T.nz * (1.0f - T.M)) * kLog2e - R.lu2;  // layers.py:918-919
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    T.Ap[r] = and_bits(ex2(au[r]), T.eb[r]);
-    T.ex1[r] = ex2(a1[r]);
+    for (int r = 0; r < 4; ++r) T.Ap[r] = and_bits(ex2(au[r]), T.eb[r]);
+  } else {
+    T.Ap = f4{0.f, 0.f, 0.f, 0.f};
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) T.ex1[r] = ex2(a1[r]);
   const f4 av = (T.P * T.ex1) * kLog2e - R.lv2;  // layers.py:920-921
 #pragma unroll
   for (int r = 0; r < 4; ++r) T.Ac[r] = and_bits(ex2(av[r]), T.eb[r]);
@@ -145,7 +152,7 @@ __device__ __forceinline__ void tile_elementwise(const RowT& R, const Consts& K,
   for (int r = 0; r < 4; ++r) T.Aw[r] = and_bits(ex2(aw[r]), T.eb[r]);
 }
 
-template <int DH>
+template <int DH, bool DCA = true>
 __device__ __forceinline__ void tile_forward(const Row<DH>& R, const Consts& K, const f4 (&k4)[DH / 16], const f4 (&ka4)[DH / 16],
                                              const f4 (&v4)[DH / 16], const f4 co4, const f4 cd4, const f4 gl, const int t,
                                              const int g, const uint32_t eb4, const uint32_t ab4, const bool order_select,
@@ -158,25 +165,31 @@ __device__ __forceinline__ void tile_forward(const Row<DH>& R, const Consts& K, 
     for (int e = 0; e < 4; ++e) {
       aS = mfma16(k4[s4][e], R.qf[4 * s4 + e], aS);
       aM = mfma16(ka4[s4][e], R.qaf[4 * s4 + e], aM);
-      aP = mfma16(v4[s4][e], R.gaf[4 * s4 + e], aP);
+      if constexpr (DCA) aP = mfma16(v4[s4][e], R.gaf[4 * s4 + e], aP);
       aW = mfma16(v4[s4][e], R.gcf[4 * s4 + e], aW);
     }
   }
-  tile_elementwise(R, K, aS, aM, aP, aW, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+  tile_elementwise<Row<DH>, DCA>(R, K, aS, aM, aP, aW, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
 }
 
 // Backward part once the row scalars are known: dS, dSa (scores), the gate-logit gradient, d o and d d of the two
 // spatial affines, and the scalar's partial.
+template <bool DCA = true>
 __device__ __forceinline__ void tile_backward(const Tile& T, const Consts& K, const float da, const float dc, const float r1,
                                               const float sP, const float sM, const f4 dMout, const int i, const int j0,
                                               f4& dS, f4& dSa, f4& dgl, f4& d_o, f4& d_d, float& dsc) {
-  const f4 du = T.Ap * (T.dAp - da);
+  f4 du = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (DCA) du = T.Ap * (T.dAp - da);
   const f4 dw = T.Aw * (T.dAw - dc);  // = d A_g
   dgl = dw * (T.P - T.Ac) * (T.gt * (1.0f - T.gt));
   const f4 dac = (1.0f - T.gt) * dw;
   const f4 dv = T.Ac * (dac - r1);
-  f4 dP = T.gt * dw + dv * T.ex1 + du * T.M;
-  f4 dM = du * (T.P - T.nz) - dv * (T.P * T.ex1) + dMout;
+  f4 dP = T.gt * dw + dv * T.ex1;
+  f4 dM = dMout - dv * (T.P * T.ex1);
+  if constexpr (DCA) {
+    dP += du * T.M;
+    dM += du * (T.P - T.nz);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {  // through the dropouts: kept entries are scaled, dropped ones carry nothing
     dP[r] = keep_and(dP[r] * K.keep_scale, T.ka, r);
@@ -417,7 +430,7 @@ __device__ __forceinline__ void key_affine(const f4 (&k4)[DH / 16], const float 
 // ---------------------------------------------------------------------------------------------------------------------
 // row kernel
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, bool DCA>
 __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acattn_bwd_row_kernel(const acattn_problem P, const acattn_bwd_io IO, float* __restrict__ ws) {
   constexpr int KS = DH / 4, DT = DH / 16;
   const int L = P.L, H = P.H, nh = P.n_heads;
@@ -565,7 +578,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     key_affine<DH>(k4, wko, wkd, g, co4, cd4);
     uint32_t eb4, ab4;
     tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
-    tile_forward<DH>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+    tile_forward<DH, DCA>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
   };
 
   // ---- sweep 1: the twelve row sums ---------------------------------------------------------------------------------
@@ -579,18 +592,23 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     const f4 alpha = T.Aw * T.dAw, beta = T.Aw;
     const f4 gam = T.Ac * (1.0f - T.gt);
     const f4 PE = T.P * T.ex1;
-    s_da += hsum(apd);
     s_dc += hsum(alpha);
     s_r1a += hsum(gam * alpha);
     s_r1b += hsum(gam * beta);
-    cP0 += hsum(T.P * (T.gt * alpha + T.ex1 * (gam * alpha) + T.M * apd));
     cPc += hsum(T.P * (T.gt * beta + T.ex1 * (gam * beta)));
     cPr += hsum(PE * T.Ac);
-    cPa += hsum(T.P * (T.M * T.Ap));
-    cM0 += hsum(T.M * ((T.P - T.nz) * apd - PE * (gam * alpha) + dMout));
     cMc += hsum(T.M * (PE * (gam * beta)));
     cMr += hsum(T.M * (PE * T.Ac));
-    cMa += hsum(T.M * ((T.P - T.nz) * T.Ap));
+    if constexpr (DCA) {
+      s_da += hsum(apd);
+      cP0 += hsum(T.P * (T.gt * alpha + T.ex1 * (gam * alpha) + T.M * apd));
+      cPa += hsum(T.P * (T.M * T.Ap));
+      cM0 += hsum(T.M * ((T.P - T.nz) * apd - PE * (gam * alpha) + dMout));
+      cMa += hsum(T.M * ((T.P - T.nz) * T.Ap));
+    } else {  // d A_p = 0: da = 0 and every term it multiplies drops out
+      cP0 += hsum(T.P * (T.gt * alpha + T.ex1 * (gam * alpha)));
+      cM0 += hsum(T.M * (dMout - PE * (gam * alpha)));
+    }
   }
   const float da = quad_sum(s_da), dc = quad_sum(s_dc);
   const float r1 = quad_sum(s_r1a) - dc * quad_sum(s_r1b);
@@ -616,7 +634,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     const f4 dMout = (dmrow ? load_seg(dmrow, j0, L, R.row_ok) : f4{0.f, 0.f, 0.f, 0.f}) + (T.M - 1.0f) * dpen2;
     f4 dS, dSa, dgl, d_o, d_d;
     float dsc;
-    tile_backward(T, K, da, dc, r1, sP, sM, dMout, R.i, j0, dS, dSa, dgl, d_o, d_d, dsc);
+    tile_backward<DCA>(T, K, da, dc, r1, sP, sM, dMout, R.i, j0, dS, dSa, dgl, d_o, d_d, dsc);
     if (full && IO.dgate_logits) store_seg(IO.dgate_logits + prow, j0, L, R.row_ok, dgl);
     da_o += hsum(d_o);
     da_d += hsum(d_d);
@@ -671,7 +689,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
 // ---------------------------------------------------------------------------------------------------------------------
 // key kernel
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, bool DCA>
 __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acattn_bwd_key_kernel(const acattn_problem P, const acattn_bwd_io IO, const float* __restrict__ ws) {
   constexpr int KS = DH / 4, DT = DH / 16;
   constexpr int TS = 20;  // row stride of a transposed 16 x 16 tile in LDS (16-byte aligned rows, conflict-free reads)
@@ -774,34 +792,37 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     uint32_t eb4, ab4;
     tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
     Tile T;
-    tile_forward<DH>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+    tile_forward<DH, DCA>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
     if (IO.d_penalty_part) dMout += (T.M - 1.0f) * (2.0f * IO.d_penalty_part[(size_t)bh * nT + qb]);
     f4 dS, dSa, dgl, d_o, d_d;
     float dsc;
-    tile_backward(T, K, w0[0], w0[1], w0[2], w0[3], sM, dMout, R.i, j0, dS, dSa, dgl, d_o, d_d, dsc);
+    tile_backward<DCA>(T, K, w0[0], w0[1], w0[2], w0[3], sM, dMout, R.i, j0, dS, dSa, dgl, d_o, d_d, dsc);
     dco += d_o;
     dcd += d_d;
     // turn the four [query c][key 4 g + r] tiles so that the query index becomes the MFMA reduction index
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     *(f4*)(&tr[0][c * TS + 4 * g]) = dS;
     *(f4*)(&tr[1][c * TS + 4 * g]) = dSa;
-    *(f4*)(&tr[2][c * TS + 4 * g]) = T.Ap;
+    if constexpr (DCA) *(f4*)(&tr[2][c * TS + 4 * g]) = T.Ap;
     *(f4*)(&tr[3][c * TS + 4 * g]) = T.Aw;
     float qc[4][DT], qac[4][DT], gac[4][DT], gcc[4][DT];
     if (full) col_frag<DH>(P.q, rowbase, H, hoff, i0, L, c, g, qc);
     col_frag<DH>(P.qa, rowbase, H, hoff, i0, L, c, g, qac);
-    if (full) col_frag<DH>(IO.d_ctx_attacked, rowbase, H, hoff, i0, L, c, g, gac);
+    if constexpr (DCA)
+      if (full) col_frag<DH>(IO.d_ctx_attacked, rowbase, H, hoff, i0, L, c, g, gac);
     if (full) col_frag<DH>(IO.d_ctx_calibrated, rowbase, H, hoff, i0, L, c, g, gcc);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const float b_s = tr[0][(4 * g + s) * TS + c], b_sa = tr[1][(4 * g + s) * TS + c];
-      const float b_ap = tr[2][(4 * g + s) * TS + c], b_aw = tr[3][(4 * g + s) * TS + c];
+      const float b_aw = tr[3][(4 * g + s) * TS + c];
+      float b_ap = 0.f;
+      if constexpr (DCA) b_ap = tr[2][(4 * g + s) * TS + c];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         if (full) {
           aK[dt] = mfma16(qc[s][dt], b_s, aK[dt]);
-          aV[dt] = mfma16(gac[s][dt], b_ap, aV[dt]);
+          if constexpr (DCA) aV[dt] = mfma16(gac[s][dt], b_ap, aV[dt]);
           aV[dt] = mfma16(gcc[s][dt], b_aw, aV[dt]);
         }
         aKa[dt] = mfma16(qac[s][dt], b_sa, aKa[dt]);
@@ -1200,8 +1221,14 @@ int launch_stream(const acattn_problem& p, const acattn_bwd_io& io, float* ws, h
     if (rc) return rc;
   }
   const dim3 grid(p.B * p.n_heads * nT), block(64);
-  hipLaunchKernelGGL((acattn_bwd_row_kernel<DH>), grid, block, 0, stream, p, io, ws);
-  hipLaunchKernelGGL((acattn_bwd_key_kernel<DH>), grid, block, 0, stream, p, io, (const float*)ws);
+  static const bool no_dca_form = getenv("ACATTN_BWD_DCA_ALWAYS") ? atoi(getenv("ACATTN_BWD_DCA_ALWAYS")) == 0 : true;
+  if (io.d_ctx_attacked || !no_dca_form) {
+    hipLaunchKernelGGL((acattn_bwd_row_kernel<DH, true>), grid, block, 0, stream, p, io, ws);
+    hipLaunchKernelGGL((acattn_bwd_key_kernel<DH, true>), grid, block, 0, stream, p, io, (const float*)ws);
+  } else {  // [r4] no cotangent of the attacked context: no perturbed attention, no Gaussian noise (see tile_elementwise)
+    hipLaunchKernelGGL((acattn_bwd_row_kernel<DH, false>), grid, block, 0, stream, p, io, ws);
+    hipLaunchKernelGGL((acattn_bwd_key_kernel<DH, false>), grid, block, 0, stream, p, io, (const float*)ws);
+  }
   return (int)hipGetLastError();
 }
 
