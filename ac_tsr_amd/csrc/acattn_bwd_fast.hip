@@ -424,6 +424,18 @@ __global__ void __launch_bounds__(256, 2) acattn_bwd_fast_kernel(const acattn_pr
       }
       if (full)
         for (int t = 0; t < nT; ++t) store_seg(IO.dgate_logits + prow, t, f4{0.f, 0.f, 0.f, 0.f});
+    } else if (!IO.d_ctx_attacked) {
+      // [r4] no cotangent of the attacked context (every layer but the last: layers.py:1112): d A_p = 0, so the perturbed
+      // attention, its product with V and the Gaussian draws that only enter through it are not needed -- the keep bits are
+      // (wave-uniform branch; the streaming pair has the same form as a template flag, acattn_bwd_stream.hip)
+#pragma unroll
+      for (int t = 0; t < NTB; ++t) {
+        const RngGroup rg = rng_group(rkey, rng_row, (uint32_t)(4 * t + g), P.p_drop);
+        keepA |= (has_drop ? rg.keep_after : 0xFu) << (4 * t);
+        keepM |= (has_drop ? rg.keep_mask : 0xFu) << (4 * t);
+        dMa[t] = f4{0.f, 0.f, 0.f, 0.f};
+        dPa[t] = dMa[t];
+      }
     } else {
       f4 dAp[NTB], Ap[NTB], nz[NTB];
       float gaf[KS];

@@ -1126,9 +1126,13 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
   // ---- query side and key halves of the parameter gradients: lane d sums over the keys --------------------------------------
   const int stride_w = IO.part_stride ? IO.part_stride : 2 * DH, stride_s = IO.part_stride ? IO.part_stride : 4;
   // lane = (column d, part): with DH <= 32 the 64 / DH parts of a column split the keys (and the rows to zero) among them
+  // (head size 128 [r4]: two column halves, one after the other -- round 3's form wrote columns 0..63 only, and its tests
+  // read what an earlier launch had left in the reused buffer)
   constexpr int PARTS = DH <= 32 ? 64 / DH : 1;
-  {
-    const int d = lane % DH, part = lane / DH;
+  constexpr int NCH = DH > 64 ? DH / 64 : 1;
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int d = (DH > 64 ? lane : lane % DH) + 64 * ch, part = DH > 64 ? 0 : lane / DH;
     float sq = 0.f, sqa = 0.f, so = 0.f, sd = 0.f;
     constexpr int UJ = 8;  // keys per trip: their 16 loads are requested before the first is used
     for (int jb = part; jb < L; jb += PARTS * UJ) {
@@ -1165,7 +1169,7 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
       if (!ACC) IO.dqa[o] = row == i ? sqa : 0.f;
     }
     if (ACC && part == 0) IO.dqa[(rowbase + i) * H + hoff + d] += sqa;
-    if (part != 0) return;
+    if (part != 0) continue;
     IO.dw_order_part[bh * stride_w + d] = da_o * vec[0][d];
     IO.dw_dist_part[bh * stride_w + d] = da_d * vec[0][d];
     IO.dw_order_part[bh * stride_w + DH + d] = so;

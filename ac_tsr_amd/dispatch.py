@@ -39,6 +39,24 @@ _LIB.define(
     "bool attack_only, Tensor? d_penalty_part=None) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)")
 
 
+import os
+
+# ACATTN_POISON_OUTPUTS=1 (tests): every output buffer of the two operators starts as NaN instead of uninitialised memory, so
+# an output element a kernel forgets to write shows up instead of reading what an earlier launch left in a reused buffer
+# (round 4 found the one-row backward at head size 128 writing half of dq's columns that way).
+_POISON = os.environ.get("ACATTN_POISON_OUTPUTS") == "1"
+
+
+def _out_like(t: torch.Tensor) -> torch.Tensor:
+    return torch.full_like(t, float("nan")) if _POISON else torch.empty_like(t)
+
+
+def _out(*shape, device) -> torch.Tensor:
+    if _POISON:
+        return torch.full(shape, float("nan"), device=device, dtype=torch.float32)
+    return torch.empty(*shape, device=device, dtype=torch.float32)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -120,17 +138,17 @@ def _fwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
     prob = _problem(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist, b_dist, scalar, n_heads, p_drop,
                     seed, seed_tensor, gate_is_prob, affine, adversarial)
     out = _lib.FwdOut()
-    ctx_cal = torch.empty_like(q)
+    ctx_cal = _out_like(q)
     out.ctx_calibrated = _ptr(ctx_cal)
     if adversarial:
-        ctx_att = torch.empty_like(q)
-        M = torch.empty(B, n_heads, L, L, device=q.device, dtype=torch.float32)
-        stats = torch.empty(B, n_heads, L, _lib.NSTAT, device=q.device, dtype=torch.float32)
+        ctx_att = _out_like(q)
+        M = _out(B, n_heads, L, L, device=q.device)
+        stats = torch.empty(B, n_heads, L, _lib.NSTAT, device=q.device, dtype=torch.float32)  # (3 of its 8 columns are spare)
         out.ctx_attacked, out.attack_mask, out.row_stats = _ptr(ctx_att), _ptr(M), _ptr(stats)
         # sum (1 - M)^2 per (sequence, head, query block): the mask penalty without another pass over M (include/acattn.h).
         # Only when a gradient can flow (evaluation / no_grad: for L <= 64 it is one more launch behind the kernel)
         if want_penalty:
-            pen = torch.empty(B, n_heads, (L + 15) // 16, device=q.device, dtype=torch.float32)
+            pen = _out(B, n_heads, (L + 15) // 16, device=q.device)
             out.penalty_part = _ptr(pen)
         else:
             pen = q.new_empty(0)
@@ -172,12 +190,12 @@ def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
     io = _lib.BwdIO()
     io.attack_mask, io.row_stats = _ptr(attack_mask), _ptr(row_stats)
     io.d_ctx_attacked, io.d_ctx_calibrated, io.d_attack_mask = _ptr(d_ctx_attacked), _ptr(d_ctx_calibrated), _ptr(d_attack_mask)
-    dq, dk, dv, dqa, dka = (torch.empty_like(q) for _ in range(5))
+    dq, dk, dv, dqa, dka = ((_out_like(q) if not attack_only or n in (3, 4) else torch.empty_like(q)) for n in range(5))
     io.dq, io.dk, io.dv, io.dqa, io.dka = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dqa), _ptr(dka)
     io.dgate_logits = _ptr(q)  # (placeholder for the query below: only tested for NULL)
     # the three per-(b, head) partial sums share ONE [B*nh, 4*dh + 4] buffer, reduced in a single pass by the caller
     width = 4 * dh + 4
-    part = torch.empty(B * n_heads, width, device=q.device, dtype=torch.float32)
+    part = _out(B * n_heads, width, device=q.device) if not attack_only else torch.empty(B * n_heads, width, device=q.device)
     ws_bytes = int(lib.acattn_calibrated_attention_bwd_workspace_bytes(C.byref(prob)))
     ws = torch.empty(max(ws_bytes, 4) // 4, device=q.device, dtype=torch.float32)
     io.workspace = _ptr(ws)
@@ -192,7 +210,8 @@ def _bwd_cuda(q, k, v, qa, ka, gate, key_valid, causal, w_order, b_order, w_dist
     # one read position per sequence: ONE row of each sequence's gate gradient is non-zero, and the one-row form of the
     # backward adds it straight into the head-summed [B,L,L] tensor (acattn_bwd_io.dgate_summed); returned as [B,1,L,L]
     summed = bool(lib.acattn_calibrated_attention_bwd_gate_summed(C.byref(prob), C.byref(io)))
-    dgate_part = torch.empty(B, 1 if summed else n_heads, L, L, device=q.device, dtype=torch.float32)
+    dgate_part = (_out if not attack_only else torch.empty)(B, 1 if summed else n_heads, L, L, device=q.device) if _POISON else \
+        torch.empty(B, 1 if summed else n_heads, L, L, device=q.device, dtype=torch.float32)
     io.dgate_logits, io.dgate_summed = _ptr(dgate_part), int(summed)
     _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
     return dq, dk, dv, dqa, dka, dgate_part, part
