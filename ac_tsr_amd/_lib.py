@@ -57,6 +57,7 @@ class BwdIO(C.Structure):
         ("dw_order_part", _f), ("dw_dist_part", _f), ("dsmall_part", _f), ("part_stride", C.c_int32),
         ("active_qblocks", _f), ("attack_only", C.c_int32), ("workspace", _f), ("read_rows", _f),
         ("n_read_rows", C.c_int32), ("d_penalty_part", _f), ("dgate_summed", C.c_int32),
+        ("d_ctx_calibrated2", _f), ("d_penalty_part2", _f), ("dqa2", _f), ("dka2", _f),
     ]
 
 
@@ -132,6 +133,7 @@ WGRAD_MAX_GROUP = 8
 SYMBOLS = {
     "acattn_abi_version": (C.c_int, []),
     "acattn_calibrated_attention_bwd_gate_summed": (C.c_int, [C.POINTER(Problem), C.POINTER(BwdIO)]),
+    "acattn_calibrated_attention_bwd_pair_supported": (C.c_int, [C.POINTER(Problem), C.POINTER(BwdIO)]),
     "acattn_last_error": (C.c_char_p, []),
     "acattn_fwd_algorithmic_bytes": (C.c_int64, [C.POINTER(Problem)]),
     "acattn_calibrated_attention_fwd": (C.c_int, [C.POINTER(Problem), C.POINTER(FwdOut), C.c_void_p]),

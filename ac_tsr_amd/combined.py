@@ -186,9 +186,12 @@ class CombinedWalk:
     def node(self, ctx, bwd, g_cal):
         g_att = self.side.pop(id(ctx), None)
         pair = getattr(type(ctx)._forward_cls, "backward_pair", None)
+        both = None
         if g_att and pair is not None:
-            att = [g_att.get(i) for i in range(len(g_cal))]
-            res_cal, res_att = pair(ctx, list(g_cal), att, self)  # one evaluation for both sets (shared recomputation)
+            # one evaluation for both sets where the node can share the recomputation between them (None: not this time)
+            both = pair(ctx, list(g_cal), [g_att.get(i) for i in range(len(g_cal))])
+        if both is not None:
+            res_cal, res_att = both
             self.stats["pair_nodes"] += 1
         else:
             res_cal = bwd(ctx, *g_cal)

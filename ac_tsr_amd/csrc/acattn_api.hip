@@ -126,6 +126,11 @@ int acattn_calibrated_attention_bwd_gate_summed(const acattn_problem* p, const a
   return acattn_bwd_gate_summed(*p, *io) ? 1 : 0;
 }
 
+int acattn_calibrated_attention_bwd_pair_supported(const acattn_problem* p, const acattn_bwd_io* io) {
+  if (!p || !io || p->B < 1 || p->L < 1 || p->H < 1 || p->n_heads < 1) return 0;
+  return acattn_bwd_pair_supported(*p, *io) ? 1 : 0;
+}
+
 int64_t acattn_calibrated_attention_bwd_workspace_bytes(const acattn_problem* p) {
   if (!p || p->B < 1 || p->L < 1 || p->n_heads < 1) return -1;
   return acattn_bwd_stream_ws_bytes(*p);

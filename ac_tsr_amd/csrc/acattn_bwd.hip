@@ -46,7 +46,19 @@ bool acattn_bwd_gate_summed(const acattn_problem& p, const acattn_bwd_io& io) {
   return acattn_bwd_onerow_applies(p, io) || onerow_split_applies(p, io);
 }
 
+bool acattn_bwd_stream_pair_applies(const acattn_problem& p, const acattn_bwd_io& io);
+bool acattn_bwd_pair_supported(const acattn_problem& p, const acattn_bwd_io& io) {
+  // the streaming pair is what runs for L > 64 (or when pinned); L <= 64 takes the row-resident kernel, which has no second set
+  const bool streaming = g_bwd_kernel == ACATTN_BWD_STREAM || (g_bwd_kernel == ACATTN_BWD_AUTO && p.L > 64);
+  return streaming && acattn_bwd_stream_pair_applies(p, io);
+}
+
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream) {
+  if ((io.dqa2 || io.dka2 || io.d_ctx_calibrated2 || io.d_penalty_part2) && !acattn_bwd_pair_supported(p, io)) {
+    acattn_set_error("attention backward: a second cotangent set was given but this launch cannot evaluate it "
+                     "(ask acattn_calibrated_attention_bwd_pair_supported first)");
+    return -1;
+  }
   if (io.dgate_summed && !acattn_bwd_gate_summed(p, io)) {
     acattn_set_error("attention backward: dgate_summed requested but this launch does not take the one-row form "
                      "(ask acattn_calibrated_attention_bwd_gate_summed first)");

@@ -56,6 +56,7 @@ struct Row {
   static constexpr int KS = DH / 4;
   float qf[KS], qaf[KS];    // B operands of S^T = K.Q^T and Sa^T = Ka.Qa^T
   float gaf[KS], gcf[KS];   // d_ctx_attacked / d_ctx_calibrated of the row (B operands of dA^T = V.dctx^T)
+  float gcf2[KS];           // [r4] d_ctx_calibrated of the SECOND cotangent set (acattn_bwd_io.d_ctx_calibrated2), TWO only
   float ao2, ad;            // query halves of the order (exp2 domain) / distance affines
   float lx2, ly2, lu2, lv2, lw2;  // the forward's log-normalisers, exp2 domain, dead-row shift removed
   int i;
@@ -79,6 +80,7 @@ struct Tile {
   f4 Ap, Ac, Aw;    // perturbed, calibrated, combined attention
   f4 gt, ex1, nz;   // gate, exp(1 - M), noise
   f4 dAp, dAw;      // cotangents of A_p and A_w (dctx . V^T)
+  f4 dAw2;          // [r4] d A_w of the second cotangent set (TWO only)
   f4 pr, val, df;   // spatial calibrator: sigmoid(o), its log argument, distance residual
   uint32_t ka, km;  // dropout keep bits
   int eb[4];        // -1 where the key may receive probability mass
@@ -152,13 +154,13 @@ __device__ __forceinline__ void tile_elementwise(const RowT& R, const Consts& K,
   for (int r = 0; r < 4; ++r) T.Aw[r] = and_bits(ex2(aw[r]), T.eb[r]);
 }
 
-template <int DH, bool DCA = true>
+template <int DH, bool DCA = true, bool TWO = false>
 __device__ __forceinline__ void tile_forward(const Row<DH>& R, const Consts& K, const f4 (&k4)[DH / 16], const f4 (&ka4)[DH / 16],
                                              const f4 (&v4)[DH / 16], const f4 co4, const f4 cd4, const f4 gl, const int t,
                                              const int g, const uint32_t eb4, const uint32_t ab4, const bool order_select,
                                              Tile& T) {
   constexpr int KS = DH / 4;
-  f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS, aP = aS, aW = aS;
+  f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = aS, aP = aS, aW = aS, aW2 = aS;
 #pragma unroll
   for (int s4 = 0; s4 < KS / 4; ++s4) {
 #pragma unroll
@@ -167,8 +169,10 @@ __device__ __forceinline__ void tile_forward(const Row<DH>& R, const Consts& K, 
       aM = mfma16(ka4[s4][e], R.qaf[4 * s4 + e], aM);
       if constexpr (DCA) aP = mfma16(v4[s4][e], R.gaf[4 * s4 + e], aP);
       aW = mfma16(v4[s4][e], R.gcf[4 * s4 + e], aW);
+      if constexpr (TWO) aW2 = mfma16(v4[s4][e], R.gcf2[4 * s4 + e], aW2);
     }
   }
+  T.dAw2 = aW2;
   tile_elementwise<Row<DH>, DCA>(R, K, aS, aM, aP, aW, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
 }
 
@@ -230,6 +234,21 @@ __device__ __forceinline__ void mask_tile(const RowT& R, const Consts& K, const 
   dM = dMext + (M - 1.0f) * dpen2;
 #pragma unroll
   for (int r = 0; r < 4; ++r) dM[r] = keep_and(dM[r] * K.keep_scale, km, r);
+}
+
+// [r4] The SECOND cotangent set of a launch (the single-pass combined backward, ac_tsr_amd/combined.py): the attacked loss's
+// cotangents of a layer that has no attack transform upstream -- d ctx_calibrated2 (what the layer above hands down) and the
+// mask penalty's d_pen2; no attacked context, and of its gradients only dqa, dka are wanted (trainer.py:678-684).  It shares
+// the rebuilt tile with the first set: d A_p = 0 (du = 0), so dS is not needed and dSa follows from dc2, r1_2, sM2 alone.
+__device__ __forceinline__ f4 second_set_dsa(const Tile& T, const Consts& K, const float dc2, const float r1_2, const float sM2,
+                                             const f4 dMout2) {
+  const f4 dw = T.Aw * (T.dAw2 - dc2);
+  const f4 dac = (1.0f - T.gt) * dw;
+  const f4 dv = T.Ac * (dac - r1_2);
+  f4 dM = dMout2 - dv * (T.P * T.ex1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dM[r] = keep_and(dM[r] * K.keep_scale, T.km, r);
+  return (T.Mt * (dM - sM2)) * K.inv_sqrt;
 }
 
 // 4 floats of a [.., L] row at key offset j0 (rows with L % 4 != 0 are only dword aligned; the last group is ragged)
@@ -307,9 +326,10 @@ __device__ __forceinline__ void load_row(const acattn_problem& P, const acattn_b
 #pragma unroll
   for (int s4 = 0; s4 < KS / 4; ++s4) {
     const f4 tq = *(const f4*)(P.q + off + 4 * s4), ta = *(const f4*)(P.qa + off + 4 * s4);
-    f4 ga = {0.f, 0.f, 0.f, 0.f}, gc = ga;
+    f4 ga = {0.f, 0.f, 0.f, 0.f}, gc = ga, gc2 = ga;
     if (IO.d_ctx_attacked) ga = *(const f4*)(IO.d_ctx_attacked + off + 4 * s4);
     if (IO.d_ctx_calibrated) gc = *(const f4*)(IO.d_ctx_calibrated + off + 4 * s4);
+    if (IO.d_ctx_calibrated2) gc2 = *(const f4*)(IO.d_ctx_calibrated2 + off + 4 * s4);
     const f4 a = *(const f4*)(P.w_order + KS * g + 4 * s4), d = *(const f4*)(P.w_dist + KS * g + 4 * s4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -317,6 +337,7 @@ __device__ __forceinline__ void load_row(const acattn_problem& P, const acattn_b
       R.qaf[4 * s4 + e] = R.row_ok ? ta[e] : 0.f;
       R.gaf[4 * s4 + e] = R.row_ok ? ga[e] : 0.f;
       R.gcf[4 * s4 + e] = R.row_ok ? gc[e] : 0.f;
+      R.gcf2[4 * s4 + e] = R.row_ok ? gc2[e] : 0.f;
       ao += R.qf[4 * s4 + e] * a[e];
       adv += R.qf[4 * s4 + e] * d[e];
     }
@@ -430,7 +451,7 @@ __device__ __forceinline__ void key_affine(const f4 (&k4)[DH / 16], const float 
 // ---------------------------------------------------------------------------------------------------------------------
 // row kernel
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DH, bool DCA>
+template <int DH, bool DCA, bool TWO = false>
 __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acattn_bwd_row_kernel(const acattn_problem P, const acattn_bwd_io IO, float* __restrict__ ws) {
   constexpr int KS = DH / 4, DT = DH / 16;
   const int L = P.L, H = P.H, nh = P.n_heads;
@@ -578,8 +599,10 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     key_affine<DH>(k4, wko, wkd, g, co4, cd4);
     uint32_t eb4, ab4;
     tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
-    tile_forward<DH, DCA>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+    tile_forward<DH, DCA, TWO>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
   };
+  const float dpen2_2 = (TWO && IO.d_penalty_part2) ? 2.0f * IO.d_penalty_part2[(size_t)bh * nT + qb] : 0.f;  // second set
+  float s_dc2 = 0.f, s_r1a2 = 0.f, cM0_2 = 0.f;
 
   // ---- sweep 1: the twelve row sums ---------------------------------------------------------------------------------
   float s_da = 0.f, s_dc = 0.f, s_r1a = 0.f, s_r1b = 0.f, cP0 = 0.f, cPc = 0.f, cPr = 0.f, cPa = 0.f, cM0 = 0.f, cMc = 0.f,
@@ -609,22 +632,36 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
       cP0 += hsum(T.P * (T.gt * alpha + T.ex1 * (gam * alpha)));
       cM0 += hsum(T.M * (dMout - PE * (gam * alpha)));
     }
+    if constexpr (TWO) {  // the second set's three sums (its cotangent-free coefficients are the first set's)
+      const f4 alpha2 = T.Aw * T.dAw2;
+      s_dc2 += hsum(alpha2);
+      s_r1a2 += hsum(gam * alpha2);
+      cM0_2 += hsum(T.M * ((T.M - 1.0f) * dpen2_2 - PE * (gam * alpha2)));
+    }
   }
   const float da = quad_sum(s_da), dc = quad_sum(s_dc);
-  const float r1 = quad_sum(s_r1a) - dc * quad_sum(s_r1b);
+  const float r1 = quad_sum(s_r1a) - dc * quad_sum(s_r1b);  // (quad_sum of the same lane sums again below: registers, not time)
   const float sP = quad_sum(cP0) - dc * quad_sum(cPc) - r1 * quad_sum(cPr) - da * quad_sum(cPa);
-  const float sM = quad_sum(cM0) + dc * quad_sum(cMc) + r1 * quad_sum(cMr) - da * quad_sum(cMa);
+  const float q_r1b = quad_sum(s_r1b), q_cMc = quad_sum(cMc), q_cMr = quad_sum(cMr);
+  const float sM = quad_sum(cM0) + dc * q_cMc + r1 * q_cMr - da * quad_sum(cMa);
+  float dc2 = 0.f, r1_2 = 0.f, sM2 = 0.f;
+  if constexpr (TWO) {
+    dc2 = quad_sum(s_dc2);
+    r1_2 = quad_sum(s_r1a2) - dc2 * q_r1b;
+    sM2 = quad_sum(cM0_2) + dc2 * q_cMc + r1_2 * q_cMr;
+  }
   if (R.row_ok && g == 0) {
     *(f4*)wrow = f4{da, dc, r1, sP};
-    *(f4*)(wrow + 4) = f4{sM, 0.f, 0.f, 0.f};
+    *(f4*)(wrow + 4) = f4{sM, dc2, r1_2, sM2};
   }
 
   // ---- sweep 2: dS, dSa -> dq, dqa; gate partials; query halves of the parameter gradients -------------------------------
-  f4 oq[DT], oqa[DT];
+  f4 oq[DT], oqa[DT], oqa2[TWO ? DT : 1];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
     oq[dt] = f4{0.f, 0.f, 0.f, 0.f};
     oqa[dt] = oq[dt];
+    if constexpr (TWO) oqa2[dt] = oq[dt];
   }
   float da_o = 0.f, da_d = 0.f, dsc_acc = 0.f;
   for (int t = 0; t < nt; ++t) {
@@ -649,6 +686,13 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
         if (full) oq[dt] = mfma16(kc[r][dt], dS[r], oq[dt]);
         oqa[dt] = mfma16(kac[r][dt], dSa[r], oqa[dt]);
       }
+    if constexpr (TWO) {
+      const f4 dSa2 = second_set_dsa(T, K, dc2, r1_2, sM2, (T.M - 1.0f) * dpen2_2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oqa2[dt] = mfma16(kac[r][dt], dSa2[r], oqa2[dt]);
+    }
   }
   if (full && IO.dgate_logits)
     for (int t = nt; t < nT; ++t) store_seg(IO.dgate_logits + prow, 16 * t + 4 * g, L, R.row_ok, f4{0.f, 0.f, 0.f, 0.f});
@@ -663,6 +707,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
       const f4 wo_lo = *(const f4*)(P.w_order + 16 * dt + 4 * g), wd_lo = *(const f4*)(P.w_dist + 16 * dt + 4 * g);
       if (full) *(f4*)(IO.dq + off + 16 * dt) = oq[dt] + da_o * wo_lo + da_d * wd_lo;
       *(f4*)(IO.dqa + off + 16 * dt) = oqa[dt];
+      if constexpr (TWO) *(f4*)(IO.dqa2 + off + 16 * dt) = oqa2[dt];
     }
   }
   if (!full) return;  // the parameter partials are not read either
@@ -689,7 +734,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
 // ---------------------------------------------------------------------------------------------------------------------
 // key kernel
 // ---------------------------------------------------------------------------------------------------------------------
-template <int DH, bool DCA>
+template <int DH, bool DCA, bool TWO = false>
 __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acattn_bwd_key_kernel(const acattn_problem P, const acattn_bwd_io IO, const float* __restrict__ ws) {
   constexpr int KS = DH / 4, DT = DH / 16;
   constexpr int TS = 20;  // row stride of a transposed 16 x 16 tile in LDS (16-byte aligned rows, conflict-free reads)
@@ -729,11 +774,13 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
   key_affine<DH>(k4, wko, wkd, g, co4, cd4);
 
   f4 aK[DT], aKa[DT], aV[DT];  // dK^T, dKa^T, dV^T: lane (c, g) holds key 16 t + c, columns 16 dt + 4 g ..
+  f4 aKa2[TWO ? DT : 1];       // [r4] dKa^T of the second cotangent set
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) {
     aK[dt] = f4{0.f, 0.f, 0.f, 0.f};
     aKa[dt] = aK[dt];
     aV[dt] = aK[dt];
+    if constexpr (TWO) aKa2[dt] = aK[dt];
   }
   f4 dco = {0.f, 0.f, 0.f, 0.f}, dcd = dco;  // d (key half of the affines) of keys 16 t + 4 g + r, summed over queries at the end
 
@@ -792,7 +839,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     uint32_t eb4, ab4;
     tile_bits(F, t, g, R.i, L, causal, R.row_ok, R.dead, eb4, ab4);
     Tile T;
-    tile_forward<DH, DCA>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
+    tile_forward<DH, DCA, TWO>(R, K, k4, ka4, v4, co4, cd4, gl, t, g, eb4, ab4, order_select, T);
     if (IO.d_penalty_part) dMout += (T.M - 1.0f) * (2.0f * IO.d_penalty_part[(size_t)bh * nT + qb]);
     f4 dS, dSa, dgl, d_o, d_d;
     float dsc;
@@ -804,6 +851,10 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
     *(f4*)(&tr[0][c * TS + 4 * g]) = dS;
     *(f4*)(&tr[1][c * TS + 4 * g]) = dSa;
     if constexpr (DCA) *(f4*)(&tr[2][c * TS + 4 * g]) = T.Ap;
+    if constexpr (TWO && !DCA) {  // the second set's d Sa takes the slot A_p does not need (TWO comes without d ctx_attacked)
+      const float dpen2_2 = IO.d_penalty_part2 ? 2.0f * IO.d_penalty_part2[(size_t)bh * nT + qb] : 0.f;
+      *(f4*)(&tr[2][c * TS + 4 * g]) = second_set_dsa(T, K, wrow[5], wrow[6], wrow[7], (T.M - 1.0f) * dpen2_2);
+    }
     *(f4*)(&tr[3][c * TS + 4 * g]) = T.Aw;
     float qc[4][DT], qac[4][DT], gac[4][DT], gcc[4][DT];
     if (full) col_frag<DH>(P.q, rowbase, H, hoff, i0, L, c, g, qc);
@@ -826,6 +877,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
           aV[dt] = mfma16(gcc[s][dt], b_aw, aV[dt]);
         }
         aKa[dt] = mfma16(qac[s][dt], b_sa, aKa[dt]);
+        if constexpr (TWO && !DCA) aKa2[dt] = mfma16(qac[s][dt], tr[2][(4 * g + s) * TS + c], aKa2[dt]);
       }
     }
   }
@@ -849,6 +901,7 @@ __global__ void __launch_bounds__(64, DH >= ACATTN_BWD_ONE_WAVE_DH ? 1 : 2) acat
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       *(f4*)(IO.dka + o + 16 * dt) = aKa[dt];
+      if constexpr (TWO) *(f4*)(IO.dka2 + o + 16 * dt) = aKa2[dt];
       if (full) {
         const f4 wo_hi = *(const f4*)(P.w_order + DH + 16 * dt + 4 * g), wd_hi = *(const f4*)(P.w_dist + DH + 16 * dt + 4 * g);
         *(f4*)(IO.dk + o + 16 * dt) = aK[dt] + dco_c * wo_hi + dcd_c * wd_hi;
@@ -1229,6 +1282,9 @@ int launch_stream(const acattn_problem& p, const acattn_bwd_io& io, float* ws, h
   if (io.d_ctx_attacked || !no_dca_form) {
     hipLaunchKernelGGL((acattn_bwd_row_kernel<DH, true>), grid, block, 0, stream, p, io, ws);
     hipLaunchKernelGGL((acattn_bwd_key_kernel<DH, true>), grid, block, 0, stream, p, io, (const float*)ws);
+  } else if (io.dqa2) {  // [r4] ... and a second cotangent set riding on the same rebuilt tiles (second_set_dsa)
+    hipLaunchKernelGGL((acattn_bwd_row_kernel<DH, false, true>), grid, block, 0, stream, p, io, ws);
+    hipLaunchKernelGGL((acattn_bwd_key_kernel<DH, false, true>), grid, block, 0, stream, p, io, (const float*)ws);
   } else {  // [r4] no cotangent of the attacked context: no perturbed attention, no Gaussian noise (see tile_elementwise)
     hipLaunchKernelGGL((acattn_bwd_row_kernel<DH, false>), grid, block, 0, stream, p, io, ws);
     hipLaunchKernelGGL((acattn_bwd_key_kernel<DH, false>), grid, block, 0, stream, p, io, (const float*)ws);
@@ -1261,6 +1317,18 @@ int acattn_launch_bwd_onerow(const acattn_problem& p, const acattn_bwd_io& io, b
     case 128: return launch_onerow<128>(p, io, accumulate, stream);  // [r3]
   }
   return -100;
+}
+
+// acattn_bwd_io's second cotangent set (d_ctx_calibrated2 / d_penalty_part2 -> dqa2, dka2): the streaming pair's form without
+// an attacked-context cotangent, every query block on the full path (no read_rows / active_qblocks hints), dh <= 64 (at head
+// size 128 the key kernel has no registers left for it).
+bool acattn_bwd_stream_pair_applies(const acattn_problem& p, const acattn_bwd_io& io) {
+  const int dh = p.n_heads > 0 ? p.H / p.n_heads : 0;
+  return io.workspace && p.L <= 208 && (int64_t)p.B * p.n_heads * p.L * p.L < (1LL << 30) && (int64_t)p.B * p.L * p.H < (1LL << 30) &&
+         p.mask_mode == ACATTN_MASK_STRUCTURED && p.rng_mode == ACATTN_RNG_COUNTER && p.w_order && p.w_dist && p.adversarial &&
+         p.combine_option == ACATTN_COMBINE_GATE && p.two_level && (dh == 16 || dh == 32 || dh == 64) && !io.d_ctx_attacked &&
+         !io.attack_only && !io.read_rows && !io.active_qblocks && io.dqa2 && io.dka2 &&
+         (io.d_ctx_calibrated2 || io.d_penalty_part2);
 }
 
 // Returns -100 when the problem is outside this path's domain (the caller then uses the row-resident kernels).

@@ -322,7 +322,8 @@ int acattn_fwd_kernel_choice(int which);
 int acattn_bwd_kernel_choice(int which);
 int64_t acattn_bwd_stream_ws_bytes(const acattn_problem& p);
 int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStream_t stream);
-bool acattn_bwd_gate_summed(const acattn_problem& p, const acattn_bwd_io& io);  // acattn_bwd_io.dgate_summed (acattn_bwd.hip)
+bool acattn_bwd_gate_summed(const acattn_problem& p, const acattn_bwd_io& io);
+bool acattn_bwd_pair_supported(const acattn_problem& p, const acattn_bwd_io& io);  // acattn_bwd_io.dqa2 (acattn_bwd.hip)  // acattn_bwd_io.dgate_summed (acattn_bwd.hip)
 int acattn_launch_spatial_affines(const acattn_problem& p, float* affine, hipStream_t stream);
 int acattn_launch_rng(int B, int nh, int L, uint64_t seed, float p_drop, float* noise, uint8_t* keep_after,
                       uint8_t* keep_mask, uint8_t* keep_before, hipStream_t stream);

@@ -327,6 +327,56 @@ class _CalibratedAttention(torch.autograd.Function):
                                                      b_order, w_dist, b_dist, scalar, rich_ratio)
 
     @staticmethod
+    def backward_pair(ctx, g_cal, g_att):
+        """Both cotangent sets of the single-pass combined backward (combined.py) in ONE launch pair, or None when this
+        node's situation is not the one the kernels share the recomputation for (include/acattn.h: acattn_bwd_io.dqa2): the
+        calibrated set without an attacked-context / mask cotangent, the attacked set in the form it has in a layer with
+        no attack transform upstream (d ctx_calibrated and / or the penalty's row sums; only dqa, dka wanted), L > 64."""
+        cfg = ctx.cfg
+        pick = lambda g, i: g[i] if len(g) > i else None
+        d_att1, d_cal1, d_M1, d_pen1 = pick(g_cal, 0), pick(g_cal, 1), pick(g_cal, 2), pick(g_cal, 7)
+        d_att2, d_cal2, d_M2, d_pen2 = pick(g_att, 0), pick(g_att, 1), pick(g_att, 2), pick(g_att, 7)
+        if not (cfg.adversarial and getattr(ctx, "via_dispatcher", False) and ctx.state.prune_dead_work and not ctx.attack_upstream
+                and d_att1 is None and d_att2 is None and d_M1 is None and d_M2 is None and d_pen1 is None
+                and d_cal1 is not None and (d_cal2 is not None or d_pen2 is not None)
+                and ctx.read_rows is None and ctx.active_qblocks is None):
+            return None
+        (q, k, v, qa, ka, gate_logits, w_order, b_order, w_dist, b_dist, scalar, rich_ratio, M, stats) = ctx.saved_tensors
+        from . import dispatch
+        lib = _lib.load()
+        B, L, H = q.shape
+        nh, dh = cfg.n_heads, H // cfg.n_heads
+        wo, wd = w_order.reshape(-1).contiguous(), w_dist.reshape(-1).contiguous()
+        prob = dispatch._problem(q, k, v, qa, ka, gate_logits, ctx.mask.key_valid, bool(ctx.mask.causal), wo, b_order, wd, b_dist,
+                                 scalar, nh, float(ctx.p_drop), int(ctx.seed) & 0x7FFFFFFFFFFFFFFF, ctx.seed_tensor,
+                                 bool(ctx.gate_is_prob), None, True)
+        io = BwdIO()
+        d_cal1 = d_cal1.contiguous()
+        d_cal2 = None if d_cal2 is None else d_cal2.contiguous()
+        d_pen2 = None if d_pen2 is None else d_pen2.contiguous()
+        io.attack_mask, io.row_stats = _ptr(M), _ptr(stats)
+        io.d_ctx_calibrated, io.d_ctx_calibrated2, io.d_penalty_part2 = _ptr(d_cal1), _ptr(d_cal2), _ptr(d_pen2)
+        dq, dk, dv, dqa, dka, dqa2, dka2 = (torch.empty_like(q) for _ in range(7))
+        io.dq, io.dk, io.dv, io.dqa, io.dka, io.dqa2, io.dka2 = (_ptr(t) for t in (dq, dk, dv, dqa, dka, dqa2, dka2))
+        dgate_part = torch.empty(B, nh, L, L, device=q.device, dtype=torch.float32)
+        io.dgate_logits = _ptr(dgate_part)
+        width = 4 * dh + 4
+        part = torch.empty(B * nh, width, device=q.device, dtype=torch.float32)
+        ws_bytes = int(lib.acattn_calibrated_attention_bwd_workspace_bytes(C.byref(prob)))
+        ws = torch.empty(max(ws_bytes, 4) // 4, device=q.device, dtype=torch.float32)
+        io.workspace = _ptr(ws)
+        base = part.data_ptr()
+        io.dw_order_part, io.dw_dist_part, io.dsmall_part = base, base + 4 * 2 * dh, base + 4 * 4 * dh
+        io.part_stride = width
+        if not lib.acattn_calibrated_attention_bwd_pair_supported(C.byref(prob), C.byref(io)):
+            return None  # (L <= 64: the row-resident kernel; head size 128; a pinned kernel)
+        _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd (pair)")
+        res_cal = _CalibratedAttention._finish_backward(lib, False, dq, dk, dv, dqa, dka, dgate_part, part, dh, w_order, b_order,
+                                                        w_dist, b_dist, scalar, rich_ratio)
+        res_att = (None, None, None, dqa2, dka2) + (None,) * 19
+        return res_cal, res_att
+
+    @staticmethod
     def _finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh, w_order, b_order, w_dist, b_dist,
                          scalar, rich_ratio):
         """The reductions behind the backward launch: per-head gate partials and per-(b, head) parameter partials."""

@@ -171,6 +171,18 @@ typedef struct acattn_bwd_io {
                            non-zero, and writing nh dense partials of it -- 164 MB of zeros at B = 512, L = 200, 2 heads --
                            plus summing them was most of that launch): ask acattn_calibrated_attention_bwd_gate_summed()
                            first; a launch that cannot honour the request fails instead of misreading the buffer. */
+  /* ABI 27, optional: a SECOND cotangent set evaluated in the same launch (the single-pass combined backward of the two-pass
+   * protocol, recbole/trainer/trainer.py:672-686: the calibrated loss's cotangents above, the attacked loss's here).  The
+   * backward is linear in its cotangents and both sets need the same rebuilt probability tiles; the second set is taken in
+   * the form the attacked loss has in a layer with no attack transform upstream: d ctx_calibrated2 [B,L,H] and / or
+   * d_penalty_part2 [B,nh,ceil(L/16)], no attacked-context and no dense mask cotangent, and of its gradients dqa2, dka2
+   * ([B,L,H], fully overwritten) alone.  Honoured by the streaming kernels (needs `workspace`) when the FIRST set has no
+   * d_ctx_attacked either and no block hints are given: ask acattn_calibrated_attention_bwd_pair_supported() first; a launch
+   * that cannot honour a non-NULL dqa2 fails. */
+  const float* d_ctx_calibrated2;
+  const float* d_penalty_part2;
+  float* dqa2;
+  float* dka2;
 } acattn_bwd_io;
 
 /* Full-catalogue cross-entropy: ACSASRec._cal_loss for loss_type 'CE',
@@ -490,6 +502,8 @@ int acattn_adam_step(const acattn_adam_group* g, double lr, double beta1, double
  * gradient (see acattn_bwd_io.dgate_summed), 0 when the launch needs the per-head [B,nh,L,L] buffer.  Validates nothing
  * else; every other field of `io` as for the launch itself (pointers are only tested for NULL). */
 int acattn_calibrated_attention_bwd_gate_summed(const acattn_problem* p, const acattn_bwd_io* io);
+/* ABI 27: 1 when the launch will evaluate the second cotangent set of `io` (see acattn_bwd_io.dqa2), else 0. */
+int acattn_calibrated_attention_bwd_pair_supported(const acattn_problem* p, const acattn_bwd_io* io);
 
 /* ABI version of the loaded library (== ACATTN_ABI_VERSION of the header it was built from). */
 int acattn_abi_version(void);

@@ -92,6 +92,10 @@ def test_combined_trainer_takes_the_steps_of_the_two_walk_trainer(graph, L, H, n
         torch.cuda.synchronize()
         losses.append([float(x.detach()) for x in out])
         states.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+        if combined:
+            # L > 64: the first layer's attention node evaluates BOTH cotangent sets in one launch pair (acattn_bwd_io.dqa2:
+            # the streaming kernels share the rebuilt tiles); L <= 64: the row-resident kernel, one launch per set
+            assert trainer.last_walk_stats["pair_nodes"] == (1 if L > 64 else 0), trainer.last_walk_stats
     assert losses[0] == pytest.approx(losses[1], rel=1e-5, abs=1e-6)
     for k in states[0]:
         # (attack_key_transform.bias has a mathematically zero gradient -- soft-max is invariant to a per-query shift -- so
