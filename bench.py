@@ -152,6 +152,12 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None, full_len
             p.qa, p.ka, p.gate_logits = qa.data_ptr(), ka.data_ptr(), gl.data_ptr()
             p.combine_option = _lib.COMBINE["gate"]
             o.ctx_attacked, o.attack_mask, o.row_stats = ctx_a.data_ptr(), M.data_ptr(), stats.data_ptr()
+            if L > 64:
+                # as in the training step: the long form of the kernel also writes the mask penalty's row sums
+                # (acattn_fwd_out.penalty_part; at L <= 64 they are a separate launch behind the kernel, not part of it)
+                pen = torch.empty(B, nh, (L + 15) // 16, device=device)
+                o.penalty_part = pen.data_ptr()
+                keep.append(pen)
         if not os.environ.get("ACTSR_BENCH_NO_EXTRAS"):
             affine = torch.empty(B, nh, 4, 16 * ((L + 15) // 16), device=device)
             _lib.check(lib.acattn_spatial_affines(C.byref(p), affine.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
@@ -270,6 +276,25 @@ def other_configs(a, device, steps=8, warmup=3):
             rec.update(ms_per_step=round(dt * 1e3, 3), ms_per_step_wall_mean=round(wall * 1e3, 3), ms_per_step_max=round(per[-1], 3),
                        value=round(b.batch / dt, 1), unit="user-sequences/sec", steps=steps,
                        final_losses=[round(x, 4) for x in losses], finite=all(x == x for x in losses))
+            # the same step in the opt-in trainer mode that walks the autograd graph ONCE for both losses (SURVEY 8 f4,
+            # ac_tsr_amd/combined.py): same gradients; beyond L = 64 the first layer's attention backward then evaluates both
+            # cotangent sets in one launch pair
+            del trainer
+            trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model, combined_backward=True)
+            trainer.enable_graph(pool[0])
+            for i in range(warmup):
+                trainer.train_step(pool[i % 2])
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            marks[0].record()
+            for i in range(steps):
+                last = trainer.train_step(pool[i % 2])
+                marks[i + 1].record()
+            torch.cuda.synchronize()
+            per1 = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+            dt1 = per1[len(per1) // 2] * 1e-3
+            rec["combined_backward"] = {"ms_per_step": round(dt1 * 1e3, 3), "value": round(b.batch / dt1, 1),
+                                        "pair_nodes": trainer.last_walk_stats.get("pair_nodes"),
+                                        "finite": all(float(x.detach()) == float(x.detach()) for x in last)}
         except Exception as e:  # a shape that does not run must show up in the line, not end the run
             rec["error"] = f"{type(e).__name__}: {e}"[:300]
         del trainer, model, pool
