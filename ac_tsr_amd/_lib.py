@@ -122,7 +122,7 @@ class TailBwdIO(C.Structure):
 class EmbedProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("n_table_rows", C.c_int64), ("idx", _f),
                 ("table", _f), ("pos", _f), ("gamma", _f), ("beta", _f), ("eps", C.c_float), ("p_drop", C.c_float),
-                ("keep", _f), ("seed", C.c_uint64), ("seed_device", _f), ("nonzero_out", _f)]
+                ("keep", _f), ("seed", C.c_uint64), ("seed_device", _f), ("nonzero_out", _f), ("hot_id_plus1", C.c_int64)]
 
 
 EMBED_BWD_CHUNKS = 8

@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) embed_ln_bwd_kernel(const acattn_embed_pr
   const f4 gm = *(const f4*)(P.gamma + 4 * c4);
   f4 pos = {0.f, 0.f, 0.f, 0.f};
   if (P.pos) pos = *(const f4*)(P.pos + (size_t)l * H + 4 * c4);
-  f4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_b = acc_g, acc_p = acc_g;
+  f4 acc_g = {0.f, 0.f, 0.f, 0.f}, acc_b = acc_g, acc_p = acc_g, acc_hot = acc_g;
+  const int64_t hot = P.hot_id_plus1 - 1;  // -1: none
   for (int b = bc * per + rsub; b < b_end; b += RPB) {
     const int row = b * P.L + l;
     const int64_t id = safe_id(P.idx, row, P.n_table_rows);
@@ -80,9 +81,13 @@ __global__ void __launch_bounds__(256) embed_ln_bwd_kernel(const acattn_embed_pr
     const f4 dx = (gg - m1 - xh * m2) * st.y;
     acc_p += dx;
     if (d_table && id != padding_idx) {
-      float* t = d_table + id * H + 4 * c4;
+      if (id == hot) {  // [r4] the one row a fifth of all lookups hit: summed in the workgroup, one atomic per column below
+        acc_hot += dx;
+      } else {
+        float* t = d_table + id * H + 4 * c4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) unsafeAtomicAdd(t + e, dx[e]);
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(t + e, dx[e]);
+      }
     }
   }
   // fold the RPB row slots of the workgroup through LDS
@@ -105,6 +110,19 @@ __global__ void __launch_bounds__(256) embed_ln_bwd_kernel(const acattn_embed_pr
       *(f4*)(dgb_part + wg * 2 * H + H + 4 * c4) = sb;
     }
     if (d_pos_part) *(f4*)(d_pos_part + wg * H + 4 * c4) = sp;  // [BC, L, H]
+  }
+  if (hot >= 0 && d_table && hot != padding_idx) {  // (wave-uniform)
+    __syncthreads();
+    *(f4*)(red + 4 * threadIdx.x) = acc_hot;
+    __syncthreads();
+    if (rsub == 0) {
+      f4 sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < RPB; ++k) sh += *(const f4*)(red + 4 * (k * LPR + c4));
+      float* t = d_table + hot * H + 4 * c4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) unsafeAtomicAdd(t + e, sh[e]);
+    }
   }
 }
 

@@ -33,8 +33,9 @@ def _problem(idx, table, pos, gamma, beta, eps, p_drop, keep, seed, seed_tensor)
 
 class _EmbedLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, idx, table, pos, gamma, beta, eps, p_drop, keep, seed, seed_tensor, padding_idx, state):
+    def forward(ctx, idx, table, pos, gamma, beta, eps, p_drop, keep, seed, seed_tensor, padding_idx, state, hot_id=None):
         ctx.state = state
+        ctx.hot_id = hot_id
         _need_cuda("item_seq", idx, torch.int64)
         for name, t in (("item_embedding.weight", table), ("LayerNorm.weight", gamma), ("LayerNorm.bias", beta)):
             _need_cuda(name, t)
@@ -66,10 +67,12 @@ class _EmbedLayerNorm(torch.autograd.Function):
         idx, table, pos, gamma, beta, stats, keep, seed_tensor = ctx.saved_tensors
         eps, p_drop, has_pos, has_keep, seed, has_seed_t, padding_idx = ctx.args
         if ctx.state.attack_pass_only or dy is None:  # none of these parameters is an attack transform (trainer.py:678-684)
-            return (None,) * 12
+            return (None,) * 13
         lib = _lib.load()
         p = _problem(idx, table, pos if has_pos else None, gamma, beta, eps, p_drop, keep if has_keep else None, seed,
                      seed_tensor if has_seed_t else None)
+        if ctx.hot_id is not None:
+            p.hot_id_plus1 = int(ctx.hot_id) + 1  # (include/acattn.h: the row a large share of the lookups hit)
         L, H, chunks = p.L, p.H, _lib.EMBED_BWD_CHUNKS
         # the loss node's dense table gradient, if one was published in this walk: the rows are scattered into it and
         # the table gets no second gradient from here (no zero fill, no [N, H] add); else a zero-filled buffer of our own
@@ -90,7 +93,7 @@ class _EmbedLayerNorm(torch.autograd.Function):
         if want_gb:
             gb = ops.sum_rows(gb_part, 0)
             dgamma, dbeta = gb[0], gb[1]
-        return None, (None if handed is not None else d_table), d_pos, dgamma, dbeta, None, None, None, None, None, None, None
+        return None, (None if handed is not None else d_table), d_pos, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def embed_layer_norm(item_seq: torch.Tensor, item_embedding: torch.nn.Embedding,
@@ -105,7 +108,7 @@ def embed_layer_norm(item_seq: torch.Tensor, item_embedding: torch.nn.Embedding,
     y, nonzero = _EmbedLayerNorm.apply(item_seq.contiguous(), item_embedding.weight,
                                        None if position_embedding is None else position_embedding.weight, norm.weight,
                                        norm.bias, norm.eps, p, keep, seed, state.seed_tensor if keep is None else None,
-                                       item_embedding.padding_idx, state)
+                                       item_embedding.padding_idx, state, getattr(item_embedding, "_acattn_hot_id", None))
     return (y, nonzero) if return_nonzero else y
 
 

@@ -299,6 +299,9 @@ class AcBERT4Rec(SequentialRecommender):
         self.mask_token = self.n_items
         self.mask_item_length = int(self.mask_ratio * self.max_seq_length)
         self.item_embedding = nn.Embedding(self.n_items + 1, self.hidden_size, padding_idx=0)  # + the mask token
+        # a fifth of all positions look up the mask token (mask_ratio): the fused embedding backward sums that row's
+        # gradient inside each workgroup instead of adding 20k rows to it one atomic at a time (acattn_embed_problem.hot_id_plus1)
+        self.item_embedding._acattn_hot_id = self.mask_token
         if self.use_position_embedding:
             self.position_embedding = nn.Embedding(self.max_seq_length, self.hidden_size)
         self.trm_encoder = AttackRTransformerEncoder(

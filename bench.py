@@ -203,7 +203,7 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None, full_len
     alg = ops.fwd_algorithmic_bytes(B, L, H, nh, adversarial, "gate")
     achieved = alg / (best * 1e-6) / 1e9
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r03_fwd_pmc_full_length.json" if full_length else "fwd_pmc_latest.json")
+    pmc = os.path.join(ROOT, "profiles", "r04_fwd_pmc_full_length.json" if full_length else "fwd_pmc_latest.json")
     if os.path.exists(pmc) and (B, L, H, nh) == (512, 50, 64, 2):
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same kernel and shape
         # (FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950 FETCH_SIZE x2 correction applied)

@@ -262,6 +262,10 @@ typedef struct acattn_embed_problem {
   const uint64_t* seed_device;
   uint8_t* nonzero_out;   /* optional [rows]: receives idx != 0, the key-validity bytes of the structured mask
                              (abstract_recommender.py:137: attention_mask = item_seq != 0); forward only */
+  int64_t hot_id_plus1;   /* ABI 27, backward only, 0 = none: id + 1 of ONE table row that a large share of the lookups hit
+                             (AcBERT4Rec's mask token, acbert4rec.py:105-150: 20 % of all positions).  Its gradient rows are
+                             summed inside each workgroup first and added with one atomic per column and workgroup: 20,480
+                             float atomics per address on one row were 1.1 ms at B = 512, L = 200, H = 256. */
 } acattn_embed_problem;
 
 /* stats[rows,2] receives (mean, 1/std) per row for the backward. */

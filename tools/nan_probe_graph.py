@@ -11,7 +11,7 @@ torch.manual_seed(42)
 model = getattr(A, a.model)(A.DictConfig(bench.model_config(a)), A.ItemCount(a.items)).to(device)
 if a.model == "AcBERT4Rec":
     model.cloze_on_device = True  # as bench.py does: the cloze batch built with tensor ops, so that the step captures
-trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model)
+trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-4), model, combined_backward=a.combined_backward)
 model.train()
 gen = torch.Generator().manual_seed(1000)
 pool = [bench.synthetic_batch(a.batch, a.seq_len, a.items, gen, device) for _ in range(8)]
