@@ -160,6 +160,8 @@ SYMBOLS = {
     "acattn_select_layer_tail_blocks": (C.c_int, [C.c_int]),
     "acattn_adam_step": (C.c_int, [C.POINTER(AdamGroup), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _f,
                                    C.c_void_p]),
+    "acattn_dense_ce_fwd": (C.c_int, [_f, C.c_int64, C.c_int64, _f, _f, _f, C.c_void_p]),
+    "acattn_dense_ce_bwd": (C.c_int, [_f, _f, _f, _f, C.c_int64, C.c_int64, _f, C.c_void_p]),
     "acattn_step_inputs": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "acattn_sum_rows": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -294,6 +294,23 @@ int acattn_layer_tail_bwd(const acattn_tail_problem* p, const acattn_tail_saved*
   return rc;
 }
 
+int acattn_dense_ce_fwd(const float* logits, int64_t rows, int64_t N, const int64_t* target, float* lse, float* row_loss,
+                        void* stream) {
+  if (!logits || !target || !lse || !row_loss) return fail("dense CE: logits, target, lse, row_loss must be non-NULL");
+  if (rows < 1 || N < 1) return fail("dense CE: rows and N must be positive");
+  const int rc = acattn_launch_dense_ce_fwd(logits, rows, N, target, lse, row_loss, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+int acattn_dense_ce_bwd(const float* logits, const float* lse, const int64_t* target, const float* coef, int64_t rows, int64_t N,
+                        float* d_logits, void* stream) {
+  if (!logits || !lse || !target || !coef || !d_logits) return fail("dense CE backward: every pointer must be non-NULL");
+  if (rows < 1 || N < 1) return fail("dense CE: rows and N must be positive");
+  const int rc = acattn_launch_dense_ce_bwd(logits, lse, target, coef, rows, N, d_logits, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int acattn_step_inputs(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n_copies, int64_t* counter,
                        const int64_t* item_length, int64_t* last_row, int32_t n_rows, void* stream) {
   if (n_copies < 0 || n_copies > ACATTN_MAX_COPIES) return fail("step inputs: 0 .. ACATTN_MAX_COPIES copies");

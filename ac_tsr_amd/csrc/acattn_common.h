@@ -376,6 +376,10 @@ int acattn_launch_penalty_bwd(const float* m, const float* norm, const float* d_
                               hipStream_t stream);
 // zero fill by a kernel (acattn_util.hip: memset nodes inside a hipGraph proved unreliable for accumulate-into-zero buffers)
 int acattn_launch_zero(float* p, size_t n, hipStream_t stream);
+int acattn_launch_dense_ce_fwd(const float* logits, int64_t rows, int64_t N, const int64_t* target, float* lse, float* row_loss,
+                               hipStream_t stream);
+int acattn_launch_dense_ce_bwd(const float* logits, const float* lse, const int64_t* target, const float* coef, int64_t rows,
+                               int64_t N, float* d_logits, hipStream_t stream);
 int acattn_launch_step_inputs(const void* const* src, void* const* dst, const int64_t* bytes, int n, int64_t* counter,
                               const int64_t* item_length, int64_t* last_row, int n_rows, hipStream_t stream);
 int acattn_launch_penalty_partial_multi(const float* const* m, int n_masks, int64_t n, float* part, hipStream_t stream);

@@ -447,6 +447,81 @@ __global__ void __launch_bounds__(256) zero_fill_kernel(float* __restrict__ p, s
 }
 }  // namespace
 
+// acattn_dense_ce_*: cross-entropy over materialised logits (include/acattn.h).  One workgroup per row in the forward (the
+// row is read once: running maximum and rescaled sum per thread, folded through LDS); the backward is elementwise, four
+// columns per thread.
+__global__ void __launch_bounds__(256) dense_ce_fwd_kernel(const float* __restrict__ logits, long long rows, long long N,
+                                                           const long long* __restrict__ target, float* __restrict__ lse,
+                                                           float* __restrict__ row_loss) {
+  constexpr float kL2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
+  __shared__ float sm[256], ss[256];
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float* x = logits + r * N;
+    float m = -__builtin_inff(), s = 0.f;
+    for (long long n = threadIdx.x; n < N; n += 256) {
+      const float v = x[n];
+      if (v > m) {
+        s = s * __builtin_amdgcn_exp2f((m - v) * kL2e) + 1.0f;
+        m = v;
+      } else {
+        s += __builtin_amdgcn_exp2f((v - m) * kL2e);
+      }
+    }
+    sm[threadIdx.x] = m;
+    ss[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) {
+        const float m1 = sm[threadIdx.x], m2 = sm[threadIdx.x + off];
+        const float mn = fmaxf(m1, m2);
+        const float a = m1 > -__builtin_inff() ? ss[threadIdx.x] * __builtin_amdgcn_exp2f((m1 - mn) * kL2e) : 0.f;
+        const float b = m2 > -__builtin_inff() ? ss[threadIdx.x + off] * __builtin_amdgcn_exp2f((m2 - mn) * kL2e) : 0.f;
+        sm[threadIdx.x] = mn;
+        ss[threadIdx.x] = a + b;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float l = sm[0] + __builtin_amdgcn_logf(ss[0]) * kLn2;
+      const long long t = target[r];
+      lse[r] = l;
+      row_loss[r] = (t >= 0 && t < N) ? l - x[t] : __builtin_nanf("");
+    }
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) dense_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                           const long long* __restrict__ target, const float* __restrict__ coef,
+                                                           long long rows, long long N, float* __restrict__ d_logits) {
+  constexpr float kL2e = 1.44269504088896340736f;
+  const long long total = rows * N;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * 1024) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long k = i + e;
+      if (k < total) {
+        const long long r = k / N, n = k - r * N;
+        const float p = __builtin_amdgcn_exp2f((logits[k] - lse[r]) * kL2e);
+        d_logits[k] = coef[r] * (p - (n == target[r] ? 1.0f : 0.0f));
+      }
+    }
+  }
+}
+int acattn_launch_dense_ce_fwd(const float* logits, int64_t rows, int64_t N, const int64_t* target, float* lse, float* row_loss,
+                               hipStream_t stream) {
+  const unsigned blocks = (unsigned)std::min<int64_t>(rows, 8192);
+  hipLaunchKernelGGL(dense_ce_fwd_kernel, dim3(blocks), dim3(256), 0, stream, logits, (long long)rows, (long long)N,
+                     (const long long*)target, lse, row_loss);
+  return (int)hipGetLastError();
+}
+int acattn_launch_dense_ce_bwd(const float* logits, const float* lse, const int64_t* target, const float* coef, int64_t rows,
+                               int64_t N, float* d_logits, hipStream_t stream) {
+  const unsigned blocks = (unsigned)std::min<int64_t>((rows * N + 1023) / 1024, 65536);
+  hipLaunchKernelGGL(dense_ce_bwd_kernel, dim3(blocks), dim3(256), 0, stream, logits, lse, (const long long*)target, coef,
+                     (long long)rows, (long long)N, d_logits);
+  return (int)hipGetLastError();
+}
+
 // acattn_step_inputs: the copies of a step's batch tensors, the replay counter and the read positions in one launch
 // (three copyBuffer launches + two ATen elementwise launches of 4.5-5 us each per step before)
 struct StepInputs {

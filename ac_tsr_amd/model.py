@@ -433,8 +433,7 @@ class AcBERT4Rec(SequentialRecommender):
                 logging.getLogger("ac_tsr_amd").info(
                     "AcBERT4Rec: hidden_size %d: the masked-slot CE uses materialised [%d, %d] logits (faster than the "
                     "fused kernels at this width; ce_materialise_limit switches)", self.hidden_size, rows.shape[0], table.shape[0])
-            per_slot = nn.functional.cross_entropy(full_sort_scores(rows, table, self.step_state), pos_items.reshape(-1),
-                                                   reduction='none')
+            per_slot = ce.dense_cross_entropy_rows(full_sort_scores(rows, table, self.step_state), pos_items.reshape(-1))
         return torch.sum(per_slot * targets) / torch.sum(targets)
 
     def calculate_loss(self, interaction, _cloze=None, _rnds=None, _keep_emb=None):

@@ -286,6 +286,17 @@ int acattn_sum_rows(const float* x, float* out, int32_t batch, int32_t R, int32_
 int acattn_sum_rows_pair(const float* x1, float* out1, int32_t batch1, int32_t R1, int32_t C1, const float* x2, float* out2,
                          int32_t batch2, int32_t R2, int32_t C2, void* stream);
 
+/* ABI 27: cross-entropy over MATERIALISED logits [rows, N] (the masked-slot loss of AcBERT4Rec, acbert4rec.py:201-209, at the
+ * widths where the catalogue product is a library GEMM): `CrossEntropyLoss(reduction='none')` without the [rows, N]
+ * log-probabilities torch writes in the forward and the zero-filled [rows, N] tensor its backward starts from.
+ *   fwd: lse[r] = logsumexp_n logits[r, n]; row_loss[r] = lse[r] - logits[r, target[r]]  (NaN for a target outside [0, N))
+ *   bwd: d_logits[r, n] = coef[r] * (exp(logits[r, n] - lse[r]) - [n == target[r]])       (one read, one write of [rows, N])
+ * logits and d_logits contiguous fp32, target int64 [rows], lse / row_loss / coef fp32 [rows]. */
+int acattn_dense_ce_fwd(const float* logits, int64_t rows, int64_t N, const int64_t* target, float* lse, float* row_loss,
+                        void* stream);
+int acattn_dense_ce_bwd(const float* logits, const float* lse, const int64_t* target, const float* coef, int64_t rows, int64_t N,
+                        float* d_logits, void* stream);
+
 /* ABI 27: the start of a (replayed) training step in ONE launch: up to ACATTN_MAX_COPIES device-to-device copies of the
  * batch tensors into the static buffers a captured hipGraph reads (recbole/trainer/trainer.py:661 interaction.to(device)
  * ends in such buffers here), `*counter += 1` when counter != NULL (the replay counter the in-kernel RNG adds to its

@@ -145,3 +145,27 @@ def test_attacked_loss_node_without_the_direction_sweep():
         got = torch.autograd.grad(loss, [o, m])
     for x, y in zip(got, want):
         assert (x.cpu() - y.float()).abs().max() <= 1e-4 * y.abs().max() + 1e-9
+
+
+@pytest.mark.parametrize("rows,N", [(7, 33), (300, 20001), (64, 100000)])
+def test_dense_cross_entropy_equals_torch(rows, N):
+    """[r4] CrossEntropyLoss(reduction='none') over materialised logits (acattn_dense_ce_fwd / _bwd: AcBERT4Rec's masked-slot
+    loss at hidden 256, acbert4rec.py:201-209): row losses and d logits against torch's fp64 log_softmax + nll, incl. rows
+    with large logits; a target outside [0, N) gives a NaN loss, not an out-of-bounds read."""
+    from ac_tsr_amd import ce
+    g = torch.Generator().manual_seed(rows + N)
+    logits = (3.0 * torch.randn(rows, N, generator=g)).to(DEV)
+    logits[0] += 60.0
+    target = torch.randint(0, N, (rows,), generator=g).to(DEV)
+    coef = torch.randn(rows, generator=g).to(DEV)
+    x = logits.clone().requires_grad_(True)
+    loss = ce.dense_cross_entropy_rows(x, target)
+    (loss * coef).sum().backward()
+    x64 = logits.double().clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(x64, target, reduction='none')
+    (want * coef.double()).sum().backward()
+    assert (loss.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    assert (x.grad.double() - x64.grad).abs().max().item() <= 2e-6 * max(1.0, x64.grad.abs().max().item())
+    bad = target.clone()
+    bad[1] = N
+    assert torch.isnan(ce.dense_cross_entropy_rows(logits, bad)[1]) and torch.isfinite(ce.dense_cross_entropy_rows(logits, bad)[0])

@@ -141,3 +141,30 @@ def test_fused_cross_entropy_flags_labels_outside_the_catalogue():
         ok = torch.ones(32, dtype=torch.bool, device=DEV)
         ok[3] = ok[7] = False
         assert (rows[ok] - good[ok]).abs().max() <= 1e-5
+
+
+def test_step_inputs_launch_copies_counts_and_forms_the_read_positions():
+    """[r4] acattn_step_inputs: the start of a replayed step in one launch (batch copies of any alignment, replay counter + 1,
+    item_length - 1 read from the SOURCE of a tensor that is being copied)."""
+    import ctypes as C
+    from ac_tsr_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    src = [torch.randint(0, 1000, (512, 50), generator=g).to(DEV), torch.randint(1, 51, (512,), generator=g).to(DEV),
+           torch.randint(0, 255, (37,), generator=g).to(torch.uint8).to(DEV)[1:]]  # (the last one: odd size, odd address)
+    dst = [torch.zeros_like(t) for t in src]
+    counter = torch.tensor([41], dtype=torch.int64, device=DEV)
+    last = torch.empty(512, dtype=torch.int64, device=DEV)
+    n = len(src)
+    s = (C.c_void_p * n)(*(t.data_ptr() for t in src))
+    d = (C.c_void_p * n)(*(t.data_ptr() for t in dst))
+    nb = (C.c_int64 * n)(*(t.numel() * t.element_size() for t in src))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.acattn_step_inputs(s, d, nb, n, C.c_void_p(counter.data_ptr()), C.c_void_p(src[1].data_ptr()),
+                                      C.c_void_p(last.data_ptr()), 512, stream), "step_inputs")
+    torch.cuda.synchronize()
+    for a, b in zip(src, dst):
+        assert torch.equal(a, b)
+    assert counter.item() == 42 and torch.equal(last, src[1] - 1)
+    assert lib.acattn_step_inputs(s, d, nb, 7, None, None, None, 0, stream) < 0 and b"ACATTN_MAX_COPIES" in lib.acattn_last_error()
+    assert lib.acattn_step_inputs(s, d, nb, n, None, C.c_void_p(src[1].data_ptr()), None, 512, stream) < 0
