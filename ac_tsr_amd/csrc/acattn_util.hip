@@ -458,14 +458,17 @@ __global__ void __launch_bounds__(256) dense_ce_fwd_kernel(const float* __restri
   for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
     const float* x = logits + r * N;
     float m = -__builtin_inff(), s = 0.f;
-    for (long long n = threadIdx.x; n < N; n += 256) {
-      const float v = x[n];
-      if (v > m) {
-        s = s * __builtin_amdgcn_exp2f((m - v) * kL2e) + 1.0f;
-        m = v;
-      } else {
-        s += __builtin_amdgcn_exp2f((v - m) * kL2e);
+    for (long long n0 = threadIdx.x; n0 < N; n0 += 1024) {  // four loads in flight per thread
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = n0 + 256 * e < N ? x[n0 + 256 * e] : -__builtin_inff();
+      const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+      if (vm > m) {
+        s *= __builtin_amdgcn_exp2f((m - vm) * kL2e);
+        m = vm;
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += __builtin_amdgcn_exp2f((v[e] - m) * kL2e);
     }
     sm[threadIdx.x] = m;
     ss[threadIdx.x] = s;
@@ -493,17 +496,19 @@ __global__ void __launch_bounds__(256) dense_ce_fwd_kernel(const float* __restri
 __global__ void __launch_bounds__(256) dense_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                            const long long* __restrict__ target, const float* __restrict__ coef,
                                                            long long rows, long long N, float* __restrict__ d_logits) {
+  // grid (column chunks of 1024, row groups): a thread takes columns c, c + 256, c + 512, c + 768 of its rows -- coalesced
+  // dword accesses whatever the row's alignment (N = 20,001 is odd), no division per element
   constexpr float kL2e = 1.44269504088896340736f;
-  const long long total = rows * N;
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * 1024) {
+  const long long c0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float l = lse[r], cf = coef[r];
+    const long long t = target[r];
+    const float* x = logits + r * N;
+    float* d = d_logits + r * N;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const long long k = i + e;
-      if (k < total) {
-        const long long r = k / N, n = k - r * N;
-        const float p = __builtin_amdgcn_exp2f((logits[k] - lse[r]) * kL2e);
-        d_logits[k] = coef[r] * (p - (n == target[r] ? 1.0f : 0.0f));
-      }
+      const long long n = c0 + 256 * e;
+      if (n < N) d[n] = cf * (__builtin_amdgcn_exp2f((x[n] - l) * kL2e) - (n == t ? 1.0f : 0.0f));
     }
   }
 }
@@ -516,8 +521,8 @@ int acattn_launch_dense_ce_fwd(const float* logits, int64_t rows, int64_t N, con
 }
 int acattn_launch_dense_ce_bwd(const float* logits, const float* lse, const int64_t* target, const float* coef, int64_t rows,
                                int64_t N, float* d_logits, hipStream_t stream) {
-  const unsigned blocks = (unsigned)std::min<int64_t>((rows * N + 1023) / 1024, 65536);
-  hipLaunchKernelGGL(dense_ce_bwd_kernel, dim3(blocks), dim3(256), 0, stream, logits, lse, (const long long*)target, coef,
+  const dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)std::min<int64_t>(rows, 32768));
+  hipLaunchKernelGGL(dense_ce_bwd_kernel, grid, dim3(256), 0, stream, logits, lse, (const long long*)target, coef,
                      (long long)rows, (long long)N, d_logits);
   return (int)hipGetLastError();
 }

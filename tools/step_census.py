@@ -10,7 +10,8 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 want_sequence = "--sequence" in sys.argv[2:]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "ce_fwd_kernel" in r["Kernel_Name"]]
+import re
+marks = [i for i, r in enumerate(rows) if re.search(r"(^|[ :])ce_fwd_kernel<", r["Kernel_Name"])]
 if len(marks) < 3:  # (AcBERT4Rec at hidden 256: materialised logits, no fused cross-entropy launch) one Adam launch per step
     marks = [i for i, r in enumerate(rows) if "adam_step_kernel" in r["Kernel_Name"]]
 spans = list(zip(marks, marks[1:]))
