@@ -47,6 +47,7 @@ class AttackSASRecTrainer:
         self.device = next(model.parameters()).device
         self.grad_sync = grad_sync
         self._graph2 = None
+        self._graph_opt = None
         # the step state the model's autograd nodes read (which backward pass is running, replay seed counter);
         # owned by the model so that two trainers / models in one process stay independent
         self.state = getattr(model, 'step_state', None) or StepState().attach(model)
@@ -286,6 +287,14 @@ class AttackSASRecTrainer:
                     self._pass_two(outs[0])
                     self.grad_sync.pack("all")
             self.grad_sync.attach()  # from now on .grad are the flat views the captured pack() fills on every replay
+        self._graph_opt = None
+        if self.grad_sync is not None and type(self.optimizer).__module__.endswith("ac_tsr_amd.optim"):
+            # [r4] under data parallelism the collectives sit between the captured backward and the optimizer: the optimizer's
+            # ONE launch (optim.Adam over the flat views) is captured on its own and replayed behind the exchange instead of
+            # being issued eagerly (host time per step: the only eager launch left in the data-parallel step)
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt, pool=graph.pool()):
+                self.optimizer.step()
         if debug_dump:
             self._raw_graph = graph.raw_cuda_graph() if hasattr(graph, "raw_cuda_graph") else None  # hipGraph_t (diagnosis)
             graph.debug_dump(debug_dump)  # hipGraphDebugDotPrint: nodes and dependency edges as a .dot file
@@ -319,7 +328,10 @@ class AttackSASRecTrainer:
                 self.grad_sync.reduce_early(packed=True)  # on the communication stream, under the replay of pass 2
                 self._graph2.replay()
             self.grad_sync.all_reduce(packed=True)
-            self.optimizer.step()
+            if self._graph_opt is not None:
+                self._graph_opt.replay()
+            else:
+                self.optimizer.step()
         if check_nan:
             for t in self._static_out:
                 if t is not None:
