@@ -143,7 +143,7 @@ class CombinedWalk:
             edges.append(next(it) if is_tensor else (None, 0))
         return edges
 
-    def _evaluate(self, fn, grads):
+    def _evaluate(self, fn, grads, fill=True):
         """One node's backward, by hand, for the att set."""
         with torch.no_grad(), self._by_hand(), self._attack():
             if isinstance(fn, BackwardCFunction):
@@ -151,7 +151,7 @@ class CombinedWalk:
                     grads = [g if g is not None else self._zeros_for(fn, i) for i, g in enumerate(grads)]
                 out = fn.apply(*grads)
             else:
-                if any(g is None for g in grads):
+                if fill and any(g is None for g in grads):
                     grads = [g if g is not None else self._zeros_for(fn, i) for i, g in enumerate(grads)]
                 out = fn(*grads)
         return out if isinstance(out, (tuple, list)) else (out,)
@@ -175,10 +175,11 @@ class CombinedWalk:
             return
         # a plain torch node (or a custom node outside the engine's walk that the prefix did not schedule): linear, so the
         # cotangent goes through it now
-        if self._n_outputs(fn) != 1:
-            raise NotImplementedError(f"combined backward: att cotangent reached multi-output node {type(fn).__name__} by itself")
+        # (a node with several forward outputs -- native_layer_norm's mean / rstd, a split -- gets this output's cotangent and
+        # nothing for the others: by linearity two cotangents arriving at different outputs may go through one at a time)
         self.stats["pushed_through"] += 1
-        out = self._evaluate(fn, [g])
+        n_out = max(self._n_outputs(fn), nr + 1)
+        out = self._evaluate(fn, [g if i == nr else None for i in range(n_out)], fill=False)
         for (nxt, n2), g2 in zip(self._edges(fn, len(out)), out):
             self.deposit(nxt, n2, g2)
 

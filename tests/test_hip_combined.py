@@ -129,3 +129,38 @@ def test_combined_walk_with_the_data_parallel_gradient_path():
     for k in states[0]:
         scale = max(1e-3, states[0][k].abs().max().item())
         assert (states[0][k] - states[1][k]).abs().max().item() <= 2e-5 * scale, k
+
+
+@pytest.mark.parametrize("over", [dict(hidden_size=96, inner_size=192, n_heads=6), dict(use_position_embedding=True),
+                                  dict(trainable_mask_loss_weight=True, mask_loss_weight=None), dict(combine_option="fixed"),
+                                  dict(n_layers=3, n_heads=4, inner_size=128), dict(two_level=False, rich_calibrated_combine="fixed")],
+                         ids=["hidden_96_library_paths", "position_embedding", "trainable_penalty_weight", "fixed_combine",
+                              "three_layers", "one_level"])
+def test_one_walk_equals_two_walks_on_the_less_common_paths(over):
+    """Widths the hand-written chains do not cover (library GEMMs, torch LayerNorm: plain torch nodes between the custom ones),
+    position embeddings, a trainable penalty weight (never receives a gradient: recbole/trainer/trainer.py:679-684), the
+    'fixed' combine and one-level forms (general kernels), a middle layer with attack transforms upstream: the gradients of
+    one eager step in the one-walk mode equal the two-walk protocol's."""
+    g = torch.Generator().manual_seed(7)
+    B, L, N = 24, 50, 900
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.randint(1, N, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    batch = {"item_id_list": ids.to(DEV), "item_length": lens.to(DEV), "item_id": ids[torch.arange(B), lens - 1].to(DEV)}
+    grads = []
+    for combined in (False, True):
+        torch.manual_seed(11)
+        model = A.ACSASRec(A.DictConfig(_cfgd(**over)), A.ItemCount(N)).to(DEV)
+        trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), model, combined_backward=combined)
+        model.train()
+        torch.manual_seed(13)
+        model.zero_grad()
+        if combined:
+            att, cal = model.calculate_loss(batch)
+            trainer.combined_backward_walk(att, cal)
+        else:
+            att, cal = trainer._pass_one(batch)
+            trainer._pass_two(att)
+        grads.append({n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()})
+    for n in grads[0]:
+        scale = grads[0][n].abs().max().item()
+        assert (grads[0][n] - grads[1][n]).abs().max().item() <= 1e-4 * scale + 1e-8, n
