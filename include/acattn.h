@@ -104,6 +104,12 @@ typedef struct acattn_problem {
                            still the gradient of the LOGITS */
 } acattn_problem;
 
+/* Non-finite inputs: a NaN in a valid row of q, k, v, qa, ka or the gate comes out as NaN in the context rows (and, for qa /
+ * ka, the attack-mask rows) that row feeds, in every forward kernel -- the streaming kernel's translation units are built with
+ * -fno-honor-nans (no canonicalising v_max in front of the row maxima), which does not change that
+ * (tests/test_hip_onehop.py::test_a_nan_in_the_inputs_reaches_the_outputs_of_the_streaming_forward).  Rows of PADDED positions
+ * (key_valid == 0) are never read by a masked soft-max here, whereas the reference's additive -10000 would propagate a NaN
+ * sitting there. */
 typedef struct acattn_fwd_out {
   float* ctx_attacked;   /* [B,L,H] head-merged perturbed_attention . V        layers.py:677-680 via :938 */
   float* ctx_calibrated; /* [B,L,H] head-merged combined attention . V         layers.py:677-680 via :942 */
