@@ -184,6 +184,8 @@ int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const 
   return rc;
 }
 
+int acattn_full_sort_ce_products(int mode) { return acattn_ce_products_choice(mode); }
+
 static int check_ln(const acattn_ln_problem* p) {
   if (!p) return fail("ln problem is NULL");
   if (p->rows < 1) return fail("rows must be positive");

@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include <stdlib.h>
+#include <string.h>
 
 #include "acattn_common.h"
 
@@ -848,6 +849,36 @@ bool split_plan(int N, int& n_wg, int& n_left) {
   return n_left > 0 && n_left <= n_wg;
 }
 
+// [round 4] hidden 64: the sweeps of acattn_ce_bf16.hip (three-way bf16 split of every operand, six bf16 MFMAs per
+// product: fp32 accuracy at 0.375 of the matrix time) wherever six tiles per wave cover the catalogue in one round,
+// with or without leftover tiles.  g_ce_products: 0 = exact fp32 MFMA everywhere (acattn_full_sort_ce_products, or
+// ACATTN_CE_PRODUCTS=fp32), 1 = the default above, 2 = the split sweeps for every catalogue size (tests).
+int g_ce_products = -1;
+int ce_products() {
+  if (g_ce_products < 0) {
+    const char* e = getenv("ACATTN_CE_PRODUCTS");
+    g_ce_products = !e ? 1 : !strcmp(e, "fp32") ? 0 : !strcmp(e, "bf16x6_all") ? 2 : 1;
+  }
+  return g_ce_products;
+}
+
+template <int CH>
+bool ce6_plan(int N, int& n_wg, int& n_left) {
+  if (CH != 64 || ce_products() == 0) return false;
+  if (split_plan<CH>(N, n_wg, n_left)) return true;
+  if (ce_products() == 2 || pick_tiles<CH>(N) == 6) {
+    n_wg = (N + CE_NW * 96 - 1) / (CE_NW * 96);
+    n_left = 0;
+    return true;
+  }
+  return false;
+}
+
+template <int CH>
+int64_t ws_bytes_base(const acattn_ce_problem& p);
+
+inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
 template <int CH, int NTILES>
 int launch_fwd_t(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
   using C = CeCfg<CH, NTILES>;
@@ -908,6 +939,21 @@ int launch_fwd_dir_t(const acattn_ce_problem& p, void* ws, float* lse, float* ro
 
 template <int CH>
 int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, float* dir, hipStream_t stream) {
+  if constexpr (CH == 64) {
+    int n_wg, n_left;
+    const int64_t n_out = (int64_t)p.B * CH;
+    if (ce6_plan<CH>(p.N, n_wg, n_left) && (n_wg + n_left) * n_out * (int64_t)sizeof(float) <= kSlabLimit) {
+      const int n_slabs = n_wg + n_left;
+      float* slab = (float*)ws;
+      float2* part = (float2*)(slab + (size_t)n_slabs * n_out);
+      void* rows_ws = (char*)ws + align256(ws_bytes_base<CH>(p));
+      if (const int e = acattn_launch_ce6_sweep(p, nullptr, nullptr, slab, nullptr, part, rows_ws, n_wg, n_left, true, stream)) return e;
+      const size_t rlds = (size_t)(n_slabs + (256 / (CH / 4)) * CH) * sizeof(float);
+      hipLaunchKernelGGL((ce_dir_reduce_kernel<CH>), dim3(p.B), dim3(256), rlds, stream, p, (const float2*)part,
+                         (const float*)slab, n_slabs, lse, row_loss, dir);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
     const int64_t n_out = (int64_t)p.B * CH;
@@ -942,7 +988,24 @@ int launch_fwd_dir(const acattn_ce_problem& p, void* ws, float* lse, float* row_
 }
 
 template <int CH>
+int64_t ws_bytes_base(const acattn_ce_problem& p);
+
+// the regular scratch, then (hidden 64) the batch rows' operand images of the split sweeps
+template <int CH>
 int64_t ws_bytes(const acattn_ce_problem& p) {
+  const int64_t base = ws_bytes_base<CH>(p);
+  if (CH != 64 || base < 0) return base;
+  return align256(base) + acattn_ce6_rows_bytes(p);
+}
+
+template <int CH>
+int64_t ws_bytes_base(const acattn_ce_problem& p) {
+  int64_t six = 0;  // the six-tile plan without leftovers (any catalogue size when forced): slabs + (max, sum-exp) pairs
+  if constexpr (CH == 64) {
+    const int64_t n_wg6 = (p.N + CE_NW * 96 - 1) / (CE_NW * 96);
+    const int64_t b6 = n_wg6 * p.B * (CH * (int64_t)sizeof(float) + (int64_t)sizeof(float2));
+    six = b6 <= kSlabLimit ? b6 : 0;
+  }
   if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
     if (split_plan<CH>(p.N, n_wg, n_left)) {  // (sized for both forms: the slab limit may send a launch to the other one)
@@ -952,7 +1015,7 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
       const int64_t regular_wg = (p.N + CE_NW * 16 * max_tiles<CH>() - 1) / (CE_NW * 16 * max_tiles<CH>());
       const int64_t regular = std::max(regular_wg * CE_NW * p.B * (int64_t)sizeof(float2),
                                        regular_wg * p.B * (CH * (int64_t)sizeof(float) + (int64_t)sizeof(float2)));
-      return std::max(std::max(fwd, regular), dirb <= kSlabLimit ? dirb : bwd <= kSlabLimit ? bwd : 0);
+      return std::max(six, std::max(std::max(fwd, regular), dirb <= kSlabLimit ? dirb : bwd <= kSlabLimit ? bwd : 0));
     }
   }
   // forward partials: one (max, sum-exp) pair per (wave, row)
@@ -969,7 +1032,7 @@ int64_t ws_bytes(const acattn_ce_problem& p) {
   const int64_t bwd = n_wg * p.B * CH * (int64_t)sizeof(float);
   // forward-with-direction: the same slabs plus one (max, sum-exp) pair per (workgroup, row)
   const int64_t dirb = bwd <= kSlabLimit ? bwd + n_wg * p.B * (int64_t)sizeof(float2) : 0;
-  return std::max(fwd, std::max(bwd <= kSlabLimit ? bwd : 0, dirb));
+  return std::max(six, std::max(fwd, std::max(bwd <= kSlabLimit ? bwd : 0, dirb)));
 }
 
 template <int CH>
@@ -998,6 +1061,18 @@ int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss
 template <int CH>
 int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, void* ws, float* d_out, float* d_table,
                hipStream_t stream) {
+  if constexpr (CH == 64) {
+    int n_wg, n_left;
+    const int64_t n_out = (int64_t)p.B * CH;
+    if (ce6_plan<CH>(p.N, n_wg, n_left) && (n_wg + n_left) * n_out * (int64_t)sizeof(float) <= kSlabLimit) {
+      float* slab = (float*)ws;
+      void* rows_ws = (char*)ws + align256(ws_bytes_base<CH>(p));
+      if (const int e = acattn_launch_ce6_sweep(p, lse, coef, slab, d_table, nullptr, rows_ws, n_wg, n_left, false, stream)) return e;
+      hipLaunchKernelGGL(ce_bwd_reduce_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, stream, slab, n_wg + n_left,
+                         n_out, d_out);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
     const int64_t n_out = (int64_t)p.B * CH;
@@ -1034,6 +1109,12 @@ int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, 
 }
 
 }  // namespace
+
+int acattn_ce_products_choice(int mode) {
+  const int old = ce_products();
+  if (mode >= 0 && mode <= 2) g_ce_products = mode;
+  return old;
+}
 
 int64_t acattn_ce_ws_bytes(const acattn_ce_problem& p) {
   switch (p.H) {

@@ -1,0 +1,587 @@
+// Full-catalogue cross-entropy, hidden 64, with the three products on the bf16 matrix pipe at fp32 accuracy [round 4].
+//
+// Same algorithm, decomposition and outputs as acattn_ce.hip (items stationary, a wave owns 16*TILES table rows and
+// sweeps the batch; ACSASRec._cal_loss, recbole/model/sequential_recommender/acsasrec.py:117-120).  What changes is the
+// arithmetic of the products.  gfx950 has no fast fp32 matrix instruction: v_mfma_f32_16x16x4_f32 runs at the vector
+// rate, 1/16 of v_mfma_f32_16x16x32_bf16.  Every fp32 operand x is therefore split EXACTLY into three bf16 numbers,
+//     x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)      (3 x 8 = 24 significand bits)
+// and a product a.b is evaluated as the six bf16 MFMAs with i + j <= 2,
+//     a.b ~ a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0),
+// each exact in the fp32 accumulator (8 x 8 bit significands); what is dropped (a1 b2 + a2 b1 + a2 b2) is below
+// 2^-23 |a||b|, the size of ONE fp32 rounding of the product.  Six 16-cycle MFMAs of K = 32 replace eight 32-cycle
+// MFMAs of K = 4: 0.375 of the matrix time.  Measured against fp64 the results are as close as the exact-fp32 kernels'
+// (tests/test_hip_ce.py::test_split_products_are_as_accurate_as_fp32_products).
+//
+// Layouts (lane = 16 g + c).  v_mfma_f32_16x16x32_bf16: A[m = c][k = 8g + j], B[k = 8g + j][n = c], j < 8;
+// D[m = 4g + r][n = c].
+//   P1  logits^T[item, row] = E . out^T        A = Er[t][s][p]  (item 16t + c, channels 32s + 8g + j), B = rows (row c,
+//       same channels).  D: items 16t + 4g + r in registers, batch row c on the lane -- as in acattn_ce.hip, so the
+//       soft-max code is that file's.
+//   P2  d out^T[ch, row]   = E^T . dl^T        B = the dl registers as they stand: k = 8g + 4tt + r is item
+//       16(2u + tt) + 4g + r of tile pair u;  A = Ec[u][cb][p] holds the table in that item order (channel 16cb + c).
+//   P3  d E[item, ch]     += dl^T . out        sums over batch rows, which sit on the lane: dl goes through a per-wave
+//       LDS image [batch row][item] (8-byte stores of 4 items) and comes back transposed with ds_read_b64_tr_b16
+//       (A[m = item c][k = row 8g + j]); B = rows by column (channel 16cb + c, rows 8g + j).  K = 32 rows: the sweep
+//       advances in SUPER-BLOCKS of 32 batch rows, P1 / soft-max / P2 per 16-row half.
+// The table operands (both orders, three planes each) stay in registers for the whole sweep: 288 of the 512 a wave has
+// at one wave per SIMD.  The batch rows are split once per launch by ce_split_rows_kernel into the exact operand
+// images (24 slots of 64 lanes x 16 bytes per super-block) and staged through LDS per super-block.
+#include <stdlib.h>
+
+#include "acattn_common.h"
+
+namespace {
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+constexpr int CH = 64;
+constexpr int NW = 4;            // waves per workgroup
+constexpr int ES = CH + 4;       // fp32 row stride of a parked [rows][CH] tile
+constexpr int HSLOTS = 24;       // operand slots of a super-block: 12 by row ((h, s, q)), 12 by column ((q, cb))
+constexpr int HB_BYTES = HSLOTS * 64 * 16;
+
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+
+// product terms (plane of the first operand, plane of the second), smallest first
+#define CE6_TERMS(X) X(0, 2) X(1, 1) X(2, 0) X(0, 1) X(1, 0) X(0, 0)
+
+__device__ __forceinline__ f4 mfma_bf(const b8 a, const b8 b, const f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// x = p0 + p1 + p2 exactly (round-to-nearest pieces; v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split8(const float (&x)[8], b8& p0, b8& p1, b8& p2) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 a = (__bf16)x[j];
+    const float r1 = x[j] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    p0[j] = a;
+    p1[j] = b;
+    p2[j] = (__bf16)r2;
+  }
+}
+
+// One workgroup per super-block of 32 batch rows: the rows' operand images.
+//   slot (2h + s) * 3 + q,  lane (c, g): plane q of out[32 sb + 16 h + c][32 s + 8 g + j]          (P1's B operand)
+//   slot 12 + 4 q + cb,     lane (c, g): plane q of out[32 sb + 8 g + j][16 cb + c]                  (P3's B operand)
+__global__ void __launch_bounds__(256) ce_split_rows_kernel(const float* __restrict__ out, const int B, b8* __restrict__ Hb) {
+  const int sb = blockIdx.x;
+  for (int e = threadIdx.x; e < 8 * 64; e += 256) {
+    const int grp = e >> 6, lane = e & 63, c = lane & 15, g = lane >> 4;
+    float x[8];
+    if (grp < 4) {
+      const int row = 32 * sb + 16 * (grp >> 1) + c;
+      f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (row < B) {
+        v0 = *(const f4*)(out + (size_t)row * CH + 32 * (grp & 1) + 8 * g);
+        v1 = *(const f4*)(out + (size_t)row * CH + 32 * (grp & 1) + 8 * g + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = v0[j];
+        x[4 + j] = v1[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = 32 * sb + 8 * g + j;
+        x[j] = row < B ? out[(size_t)row * CH + 16 * (grp - 4) + c] : 0.f;
+      }
+    }
+    b8 p[3];
+    split8(x, p[0], p[1], p[2]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int slot = grp < 4 ? grp * 3 + q : 12 + 4 * q + (grp - 4);
+      Hb[((size_t)sb * HSLOTS + slot) * 64 + lane] = p[q];
+    }
+  }
+}
+
+template <int TILES>
+struct Ce6 {
+  static_assert(TILES % 2 == 0, "P2 takes the item tiles in pairs (K = 32)");
+  static constexpr int ITEMS = 16 * TILES;
+  static constexpr int UP = TILES / 2;
+  static constexpr int XRS = 2 * ITEMS + 8;            // bytes per batch row of the transpose image (8-byte aligned, 50 dwords at 6 tiles)
+  static constexpr int XPLANE = 32 * XRS;
+  static constexpr int XBYTES_RAW = 3 * XPLANE;
+  // the leftover units' working set (acattn_ce.hip's: a tile's rows, a row block, a transpose scratch, fp32) shares the area
+  static constexpr int LEFT_BYTES = (32 * ES + 16 * 48) * 4;
+  static constexpr int XBYTES = ((XBYTES_RAW > LEFT_BYTES ? XBYTES_RAW : LEFT_BYTES) + 15) / 16 * 16;
+  static constexpr int PARK_FLOATS = 32 * ES;          // per wave
+  static constexpr int LDS_BYTES = HB_BYTES + NW * XBYTES + NW * PARK_FLOATS * 4;
+};
+
+// DIR as in acattn_ce.hip: a forward that also yields the direction of d_out (running maxima per wave, folded per
+// workgroup, finished by ce_dir_reduce_kernel).
+template <int TILES, bool WITH_TABLE_GRAD, bool DIR>
+__global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_problem P, const float* __restrict__ lse,
+                                                          const float* __restrict__ coef, float* __restrict__ d_out_slab,
+                                                          float* __restrict__ d_table, float2* __restrict__ part,
+                                                          const b8* __restrict__ Hb, const int n_left) {
+  static_assert(!(DIR && WITH_TABLE_GRAD), "the forward-with-direction sweep has no table gradient");
+  using C = Ce6<TILES>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int item0 = (blockIdx.x * NW + wave) * C::ITEMS;
+  const int B = P.B, N = P.N;
+  const bool ragged = item0 + C::ITEMS > N;  // (uniform per wave)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  b8* Hs = (b8*)smem;                                       // [24][64] operand images of the current super-block
+  char* Xw = smem + HB_BYTES + wave * C::XBYTES;            // this wave's transpose image, 3 planes [32 rows][XRS]
+  float* park = (float*)(smem + HB_BYTES + NW * C::XBYTES); // [NW][32][ES] parked d_out tiles
+  float* Pw = park + wave * C::PARK_FLOATS;
+
+  // ---- the wave's table rows, split, in both operand orders -------------------------------------------------------
+  b8 Er[TILES][2][3];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) {
+    const int item = item0 + 16 * t + c;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (item < N) {
+        v0 = *(const f4*)(P.table + (size_t)item * CH + 32 * s + 8 * g);
+        v1 = *(const f4*)(P.table + (size_t)item * CH + 32 * s + 8 * g + 4);
+      }
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = v0[j];
+        x[4 + j] = v1[j];
+      }
+      split8(x, Er[t][s][0], Er[t][s][1], Er[t][s][2]);
+    }
+  }
+  b8 Ec[C::UP][4][3];
+#pragma unroll
+  for (int u = 0; u < C::UP; ++u) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int item = item0 + 16 * (2 * u + (j >> 2)) + 4 * g + (j & 3);
+        x[j] = item < N ? P.table[(size_t)item * CH + 16 * cb + c] : 0.f;
+      }
+      split8(x, Ec[u][cb][0], Ec[u][cb][1], Ec[u][cb][2]);
+    }
+  }
+  f4 dE[TILES][4];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) dE[t][cb] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsb = (B + 31) >> 5;
+  constexpr int HV = HB_BYTES / 16 / (64 * NW);  // 16-byte pieces of a super-block's images per thread (6)
+  f4 h_next[HV];
+  float lse_next[2] = {0.f, 0.f}, cf_next[2] = {0.f, 0.f};
+  int tgt_next[2] = {-1, -1};
+  auto prefetch = [&](int sb) {
+    const f4* src = (const f4*)Hb + (size_t)sb * (HB_BYTES / 16);
+#pragma unroll
+    for (int u = 0; u < HV; ++u) h_next[u] = src[threadIdx.x + u * 64 * NW];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 32 * sb + 16 * h + c;
+      const bool ok = row < B;
+      lse_next[h] = (ok && !DIR) ? lse[row] : 0.f;
+      cf_next[h] = (ok && !DIR) ? coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f) : 0.f;
+      tgt_next[h] = ok ? (int)P.target[row] : -1;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < HV; ++u) ((f4*)Hs)[threadIdx.x + u * 64 * NW] = h_next[u];
+  };
+  prefetch(0);
+  stage();
+  float l2_cur[2], cf_cur[2];
+  int tgt_cur[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    l2_cur[h] = lse_next[h] * kLog2e;
+    cf_cur[h] = cf_next[h];
+    tgt_cur[h] = tgt_next[h];
+  }
+  if (nsb > 1) prefetch(1);
+  __syncthreads();
+
+  for (int sb = 0; sb < nsb; ++sb) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool row_ok = 32 * sb + 16 * h + c < B;
+      // ---- P1: logits^T of the wave's items for the half's 16 rows -------------------------------------------------
+      b8 Hr[2][3];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Hr[s][q] = Hs[((2 * h + s) * 3 + q) * 64 + lane];
+      f4 dl[TILES];
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) dl[t] = f4{0.f, 0.f, 0.f, 0.f};
+#define CE6_P1(p, q)                                                                  \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s)                                      \
+      _Pragma("unroll") for (int t = 0; t < TILES; ++t) dl[t] = mfma_bf(Er[t][s][p], Hr[s][q], dl[t]);
+      CE6_TERMS(CE6_P1)
+#undef CE6_P1
+      // ---- soft-max arithmetic (acattn_ce.hip's, the layout is the same) -------------------------------------------
+      if (ragged) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (item0 + 16 * t + 4 * g + r >= N) dl[t][r] = ACATTN_NEG_INF;  // exp2(-inf) = 0 past the catalogue end
+      }
+      float m_w = ACATTN_NEG_INF, s_w = 0.f;  // DIR: this wave's maximum and sum-exp for batch row c
+      if (DIR) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) m_w = fmaxf(fmaxf(fmaxf(fmaxf(m_w, dl[t][0]), dl[t][1]), dl[t][2]), dl[t][3]);
+        m_w = quad_max(m_w);
+        const float m2 = m_w > ACATTN_NEG_INF ? m_w * kLog2e : 0.f;
+        f4 sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          f4 x = dl[t] * kLog2e - m2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+          dl[t] = x;
+          sv += x;
+        }
+        s_w = quad_sum((sv[0] + sv[1]) + (sv[2] + sv[3]));
+      } else {
+        const int tgt = row_ok ? tgt_cur[h] - item0 : -1;  // target as an index into this wave's items
+        const int t_t = tgt >> 4, g_t = (tgt >> 2) & 3, r_t = tgt & 3;
+        const bool mine = tgt >= 0 && tgt < C::ITEMS && g_t == g;
+        const float l2 = l2_cur[h], cf = cf_cur[h];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          f4 x = dl[t] * kLog2e - l2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+          if (mine && t == t_t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] -= (r == r_t) ? 1.0f : 0.0f;
+          }
+          dl[t] = x * cf;
+        }
+      }
+      // ---- split dl; its planes are P2's B operand as they stand, and go to the transpose image for P3 -------------
+      b8 dlB[C::UP][3];
+#pragma unroll
+      for (int u = 0; u < C::UP; ++u) {
+        float x[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          x[r] = dl[2 * u][r];
+          x[4 + r] = dl[2 * u + 1][r];
+        }
+        split8(x, dlB[u][0], dlB[u][1], dlB[u][2]);
+      }
+      if (WITH_TABLE_GRAD) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int u = 0; u < C::UP; ++u) {
+            char* dst = Xw + p * C::XPLANE + (16 * h + c) * C::XRS + (32 * u + 4 * g) * 2;
+            *(b4*)dst = __builtin_shufflevector(dlB[u][p], dlB[u][p], 0, 1, 2, 3);         // items 16(2u) + 4g ..
+            *(b4*)(dst + 32) = __builtin_shufflevector(dlB[u][p], dlB[u][p], 4, 5, 6, 7);  // items 16(2u + 1) + 4g ..
+          }
+      }
+      // ---- P2: d out^T (this wave's items) = E^T . dl^T -------------------------------------------------------------
+      f4 dh[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) dh[cb] = f4{0.f, 0.f, 0.f, 0.f};
+#define CE6_P2(p, q)                                                                  \
+  _Pragma("unroll") for (int u = 0; u < C::UP; ++u)                                  \
+      _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) dh[cb] = mfma_bf(Ec[u][cb][p], dlB[u][q], dh[cb]);
+      CE6_TERMS(CE6_P2)
+#undef CE6_P2
+      // park the half's [16][CH] tile for the fold
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) *(f4*)(Pw + (16 * h + c) * ES + 16 * cb + 4 * g) = dh[cb];
+      if (DIR && g == 0) {  // (max, sum-exp) of this wave for the row, in the pad columns of its parked tile
+        Pw[(16 * h + c) * ES + CH] = m_w;
+        Pw[(16 * h + c) * ES + CH + 1] = s_w;
+      }
+    }
+    if (WITH_TABLE_GRAD) {
+      // ---- P3: d E (this wave's items) += dl^T . out over the super-block's 32 rows --------------------------------
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is the wave's own: its stores have landed, no barrier
+      b8 Hc[3][4];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) Hc[q][cb] = Hs[(12 + 4 * q + cb) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        b8 At[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          // lane 4q' + p' of a 16-lane group addresses row q', columns 4p' .. of the block; receives column c, rows 0..3
+          const char* src = Xw + p * C::XPLANE + (8 * g + (c >> 2)) * C::XRS + (16 * t + 4 * (c & 3)) * 2;
+          const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(src));
+          const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(src + 4 * C::XRS));
+          const s8v both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          At[p] = __builtin_bit_cast(b8, both);
+        }
+#define CE6_P3(p, q) \
+  _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) dE[t][cb] = mfma_bf(At[p], Hc[q][cb], dE[t][cb]);
+        CE6_TERMS(CE6_P3)
+#undef CE6_P3
+      }
+    }
+    __syncthreads();  // every wave's tiles are parked; nobody reads the operand images any more
+    // next super-block's images, then the fold of this one's d_out tiles (each thread sums float4s of the four waves)
+    if (sb + 1 < nsb) {
+      stage();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        l2_cur[h] = lse_next[h] * kLog2e;
+        cf_cur[h] = cf_next[h];
+        tgt_cur[h] = tgt_next[h];
+      }
+      if (sb + 2 < nsb) prefetch(sb + 2);
+    }
+    for (int idx = threadIdx.x; idx < 32 * (CH / 4); idx += 64 * NW) {
+      const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+      if (32 * sb + r < B) {
+        f4 sum = {0.f, 0.f, 0.f, 0.f};
+        const size_t o = (size_t)(32 * sb + r) * CH + 4 * c4;
+        if (DIR) {
+          float mw[NW], m_wg = ACATTN_NEG_INF;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            mw[w] = park[w * C::PARK_FLOATS + r * ES + CH];
+            m_wg = fmaxf(m_wg, mw[w]);
+          }
+          float s_wg = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            const float sc = mw[w] > ACATTN_NEG_INF ? __builtin_amdgcn_exp2f((mw[w] - m_wg) * kLog2e) : 0.f;
+            sum += *(const f4*)(park + w * C::PARK_FLOATS + r * ES + 4 * c4) * sc;
+            s_wg += park[w * C::PARK_FLOATS + r * ES + CH + 1] * sc;
+          }
+          *(f4*)(d_out_slab + (size_t)blockIdx.x * B * CH + o) = sum;
+          if (c4 == 0) part[(size_t)blockIdx.x * B + 32 * sb + r] = float2{m_wg, s_wg};
+          continue;
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += *(const f4*)(park + w * C::PARK_FLOATS + r * ES + 4 * c4);
+        *(f4*)(d_out_slab + (size_t)blockIdx.x * B * CH + o) = sum;
+      }
+    }
+    __syncthreads();  // the images are staged, the parked tiles are free
+  }
+  if (WITH_TABLE_GRAD) {
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int item = item0 + 16 * t + 4 * g + r;
+        if (item < N) {
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) d_table[(size_t)item * CH + 16 * cb + c] = dE[t][cb][r];
+        }
+      }
+  }
+  if (n_left > 0) {
+    // Leftover units (tile, 16-row block) behind the whole rounds, exactly acattn_ce.hip's scheme and arithmetic (exact
+    // fp32 MFMA: a quarter sweep of one tile per wave at most).  Results: slab / partial number gridDim.x + tile.
+    constexpr int KS = CH / 4, DT = CH / 16;
+    const int nrb = (B + 15) >> 4;
+    const int wid = blockIdx.x * NW + wave;
+    int first, stride, n_my;
+    if (WITH_TABLE_GRAD) {
+      first = blockIdx.x * nrb + wave;
+      stride = NW;
+      n_my = (int)blockIdx.x < n_left ? (nrb - wave + NW - 1) / NW : 0;
+    } else {
+      const int n_units = n_left * nrb, U = (n_units + gridDim.x * NW - 1) / (gridDim.x * NW);
+      first = wid * U;
+      stride = 1;
+      n_my = min(max(n_units - first, 0), U);
+    }
+    constexpr int TSX = 48;  // 16 * odd
+    float* Ex = (float*)Xw;       // [16][ES] the leftover tile's table rows
+    float* Hx = Ex + 16 * ES;     // [16][ES] this wave's batch rows
+    float* Xx = Hx + 16 * ES;     // [16][TSX] transpose scratch
+    f4 dEx[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dEx[dt] = f4{0.f, 0.f, 0.f, 0.f};
+    constexpr int HX = 16 * (CH / 4) / 64;
+    constexpr int GU = 4;
+    f4 hx_g[GU][HX];
+    float lse_g[GU], cf_g[GU];
+    int tgt_g[GU];
+    auto prefetch_x = [&](int q, int rb) {
+#pragma unroll
+      for (int u = 0; u < HX; ++u) {
+        const int idx = lane + 64 * u;
+        const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+        hx_g[q][u] = f4{0.f, 0.f, 0.f, 0.f};
+        if (16 * rb + r < B) hx_g[q][u] = *(const f4*)(P.out + (size_t)(16 * rb + r) * CH + 4 * c4);
+      }
+      const int row = 16 * rb + c;
+      const bool ok = row < B;
+      lse_g[q] = (ok && !DIR) ? lse[row] : 0.f;
+      cf_g[q] = (ok && !DIR) ? coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f) : 0.f;
+      tgt_g[q] = ok ? (int)P.target[row] : -1;
+    };
+    int cur_tile = -1;
+    for (int k0 = 0; k0 < n_my; k0 += GU) {
+#pragma unroll
+      for (int q = 0; q < GU; ++q)
+        if (k0 + q < n_my) prefetch_x(q, (first + (k0 + q) * stride) % nrb);
+#pragma unroll
+      for (int q = 0; q < GU; ++q) {
+        if (k0 + q >= n_my) break;
+        const int u = first + (k0 + q) * stride, tile = u / nrb, rb = u - tile * nrb;
+        const int itx = gridDim.x * NW * C::ITEMS + 16 * tile;
+        const size_t vslab = (size_t)(gridDim.x + tile) * B;
+        if (tile != cur_tile) {  // (uniform per wave)
+          cur_tile = tile;
+          for (int idx = lane; idx < 16 * (CH / 4); idx += 64) {
+            const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (itx + r < N) v = *(const f4*)(P.table + (size_t)(itx + r) * CH + 4 * c4);
+            *(f4*)(Ex + r * ES + 4 * c4) = v;
+          }
+        }
+#pragma unroll
+        for (int w = 0; w < HX; ++w) {
+          const int idx = lane + 64 * w;
+          const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
+          *(f4*)(Hx + r * ES + 4 * c4) = hx_g[q][w];
+        }
+        const int row = 16 * rb + c;
+        const bool ok = row < B;
+        const float l2 = lse_g[q] * kLog2e;
+        const float cf = cf_g[q];
+        const int tgt = ok ? tgt_g[q] - itx : -1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float hf[KS];
+#pragma unroll
+        for (int s4 = 0; s4 < KS / 4; ++s4) {
+          const f4 v = *(const f4*)(Hx + c * ES + KS * g + 4 * s4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hf[4 * s4 + e] = v[e];
+        }
+        f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int s4 = 0; s4 < KS / 4; ++s4) {
+          const f4 e4 = *(const f4*)(Ex + c * ES + KS * g + 4 * s4);
+          a0 = mfma16(e4[0], hf[4 * s4 + 0], a0);
+          a1 = mfma16(e4[1], hf[4 * s4 + 1], a1);
+          a0 = mfma16(e4[2], hf[4 * s4 + 2], a0);
+          a1 = mfma16(e4[3], hf[4 * s4 + 3], a1);
+        }
+        f4 dlx = a0 + a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (itx + 4 * g + r >= N) dlx[r] = ACATTN_NEG_INF;
+        float m_w = ACATTN_NEG_INF, s_w = 0.f;
+        if (DIR) {
+          m_w = quad_max(fmaxf(fmaxf(dlx[0], dlx[1]), fmaxf(dlx[2], dlx[3])));
+          const float m2 = m_w > ACATTN_NEG_INF ? m_w * kLog2e : 0.f;
+          f4 x = dlx * kLog2e - m2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+          dlx = x;
+          s_w = quad_sum((x[0] + x[1]) + (x[2] + x[3]));
+        } else {
+          f4 x = dlx * kLog2e - l2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+          if (tgt >= 0 && tgt < 16 && ((tgt >> 2) & 3) == g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] -= (r == (tgt & 3)) ? 1.0f : 0.0f;
+          }
+          dlx = x * cf;
+        }
+        f4 dh[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dh[dt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const float* ep = Ex + (4 * g + kk) * ES + c;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) dh[dt] = mfma16(ep[16 * dt], dlx[kk], dh[dt]);
+        }
+        if (ok) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) *(f4*)(d_out_slab + (vslab + row) * CH + 16 * dt + 4 * g) = dh[dt];
+          if (DIR && g == 0) part[vslab + row] = float2{m_w, s_w};
+        }
+        if (WITH_TABLE_GRAD) {
+          *(f4*)(Xx + c * TSX + 4 * g) = dlx;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int sr = 0; sr < 4; ++sr) {
+            const float at = Xx[(4 * sr + g) * TSX + c];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dEx[dt] = mfma16(at, Hx[(4 * sr + g) * ES + 16 * dt + c], dEx[dt]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+    }
+    if (WITH_TABLE_GRAD && (int)blockIdx.x < n_left) {  // the four waves' shares of the tile's d_table rows meet in the parked-tile areas
+      const int itx = gridDim.x * NW * C::ITEMS + 16 * blockIdx.x;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pw[(4 * g + r) * ES + 16 * dt + c] = dEx[dt][r];
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 16 * CH; idx += 64 * NW) {
+        const int i = idx / CH, hcol = idx - i * CH;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += park[w * C::PARK_FLOATS + i * ES + hcol];
+        if (itx + i < N) d_table[(size_t)(itx + i) * CH + hcol] = v;
+      }
+    }
+  }
+}
+
+template <class K>
+void allow_lds(K k, size_t lds) {
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+}  // namespace
+
+// Bytes of the batch rows' operand images (behind the regular workspace of acattn_ce.hip).
+int64_t acattn_ce6_rows_bytes(const acattn_ce_problem& p) { return (int64_t)((p.B + 31) / 32) * HB_BYTES; }
+
+// n_wg workgroups of 4 waves x 6 tiles (+ n_left leftover tiles); slab / part as in acattn_ce.hip's launchers.
+int acattn_launch_ce6_sweep(const acattn_ce_problem& p, const float* lse, const float* coef, float* slab, float* d_table,
+                            float2* part, void* rows_ws, int n_wg, int n_left, bool dir, hipStream_t stream) {
+  using C = Ce6<6>;
+  b8* Hb = (b8*)rows_ws;
+  hipLaunchKernelGGL(ce_split_rows_kernel, dim3((p.B + 31) / 32), dim3(256), 0, stream, p.out, p.B, Hb);
+  const size_t lds = C::LDS_BYTES;
+  if (dir) {
+    auto k = ce6_bwd_kernel<6, false, true>;
+    allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * NW), lds, stream, p, lse, coef, slab, d_table, part, (const b8*)Hb, n_left);
+  } else if (d_table) {
+    auto k = ce6_bwd_kernel<6, true, false>;
+    allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * NW), lds, stream, p, lse, coef, slab, d_table, part, (const b8*)Hb, n_left);
+  } else {
+    auto k = ce6_bwd_kernel<6, false, false>;
+    allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3(n_wg), dim3(64 * NW), lds, stream, p, lse, coef, slab, d_table, part, (const b8*)Hb, n_left);
+  }
+  return (int)hipGetLastError();
+}

@@ -376,6 +376,11 @@ int acattn_launch_penalty_bwd(const float* m, const float* norm, const float* d_
                               hipStream_t stream);
 // zero fill by a kernel (acattn_util.hip: memset nodes inside a hipGraph proved unreliable for accumulate-into-zero buffers)
 int acattn_launch_zero(float* p, size_t n, hipStream_t stream);
+// acattn_ce_bf16.hip: the hidden-64 sweeps with split (3 x bf16) operands
+int64_t acattn_ce6_rows_bytes(const acattn_ce_problem& p);
+int acattn_launch_ce6_sweep(const acattn_ce_problem& p, const float* lse, const float* coef, float* slab, float* d_table,
+                            float2* part, void* rows_ws, int n_wg, int n_left, bool dir, hipStream_t stream);
+int acattn_ce_products_choice(int mode);
 int acattn_launch_dense_ce_fwd(const float* logits, int64_t rows, int64_t N, const int64_t* target, float* lse, float* row_loss,
                                hipStream_t stream);
 int acattn_launch_dense_ce_bwd(const float* logits, const float* lse, const int64_t* target, const float* coef, int64_t rows,

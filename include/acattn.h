@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 27
+#define ACATTN_ABI_VERSION 28
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -223,6 +223,21 @@ int acattn_full_sort_ce_fwd_dir(const acattn_ce_problem* p, void* workspace, flo
 /* Gradients of sum_b coef[b] * row_loss[b]: d_out [B,H] always; d_table [N,H] (fully overwritten) unless NULL. */
 int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const float* coef, void* workspace,
                             float* d_out, float* d_table, void* stream);
+
+/* [ABI 28] How the three products of the full-catalogue cross-entropy are evaluated at hidden 64 (acattn_ce_bf16.hip).
+ * gfx950's fp32 matrix instruction runs at 1/16 of the bf16 one, so the default splits every fp32 operand exactly
+ * into three bf16 numbers and evaluates a product as the six bf16 MFMAs whose dropped remainder is below 2^-23 of
+ * |a||b| -- one fp32 rounding; results are as close to fp64 as the exact-fp32 kernels' (tests/test_hip_ce.py).
+ *   ACATTN_CE_PRODUCTS_FP32 (0)    exact fp32 MFMA everywhere (round 3's kernels; also ACATTN_CE_PRODUCTS=fp32)
+ *   ACATTN_CE_PRODUCTS_DEFAULT (1) the split sweeps wherever six item tiles per wave cover the catalogue in one round
+ *                                  (81,921 .. 102,400 items on 256 CUs), the fp32 kernels elsewhere
+ *   ACATTN_CE_PRODUCTS_ALL (2)     the split sweeps for every catalogue size (tests)
+ * Process-wide; returns the previous mode; any other value only queries.  Non-finite inputs: an infinite operand splits
+ * into inf + nan, so an infinite logit becomes NaN instead of inf (the loss is non-finite either way). */
+#define ACATTN_CE_PRODUCTS_FP32 0
+#define ACATTN_CE_PRODUCTS_DEFAULT 1
+#define ACATTN_CE_PRODUCTS_ALL 2
+int acattn_full_sort_ce_products(int mode);
 
 /* y = LayerNorm(dropout(z) + residual) * gamma + beta   (the tail of both sub-blocks
  * of a layer -- recbole/model/layers.py:681-683 and :794-796).  Rows of H in {64, 128, 256} floats. */
