@@ -52,6 +52,14 @@ __device__ __forceinline__ f4 mfma_bf(const b8 a, const b8 b, const f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// One wave-wide LDS-DMA: lane l copies the 16 bytes at gsrc (per lane) to LDS byte address lds_dst + 16 l (lds_dst
+// wave-uniform, in M0) without passing through registers.  Inline assembly as in acattn_fwd_dma.hip: the kernel orders
+// the copies itself (s_waitcnt vmcnt(0) in front of the barrier that publishes them).
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
+  const uint32_t lds_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory", "m0");
+}
+
 // x = p0 + p1 + p2 exactly (round-to-nearest pieces; v_cvt_pk_bf16_f32)
 __device__ __forceinline__ void split8(const float (&x)[8], b8& p0, b8& p1, b8& p2) {
 #pragma unroll
@@ -103,6 +111,22 @@ __global__ void __launch_bounds__(256) ce_split_rows_kernel(const float* __restr
   }
 }
 
+// Diagnostic builds only (-DACATTN_CE_STAMPS, tools/gpu_ce6_stamps.sh): cycles per phase, summed per wave.
+#ifdef ACATTN_CE_STAMPS
+__device__ unsigned long long g_ce6_stamps[4096 * 8];
+#define CE6_STAMP(k)                                                               \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    unsigned long long now_;                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");   \
+    if ((k) >= 0) cyc_[(k) >= 0 ? (k) : 0] += now_ - last_;                        \
+    last_ = now_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#else
+#define CE6_STAMP(k)
+#endif
+
 template <int TILES>
 struct Ce6 {
   static_assert(TILES % 2 == 0, "P2 takes the item tiles in pairs (K = 32)");
@@ -115,7 +139,8 @@ struct Ce6 {
   static constexpr int LEFT_BYTES = (32 * ES + 16 * 48) * 4;
   static constexpr int XBYTES = ((XBYTES_RAW > LEFT_BYTES ? XBYTES_RAW : LEFT_BYTES) + 15) / 16 * 16;
   static constexpr int PARK_FLOATS = 32 * ES;          // per wave
-  static constexpr int LDS_BYTES = HB_BYTES + NW * XBYTES + NW * PARK_FLOATS * 4;
+  static constexpr int LDS_BYTES = 2 * HB_BYTES + NW * XBYTES + NW * PARK_FLOATS * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 };
 
 // DIR as in acattn_ce.hip: a forward that also yields the direction of d_out (running maxima per wave, folded per
@@ -135,11 +160,15 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
   const bool ragged = item0 + C::ITEMS > N;  // (uniform per wave)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  b8* Hs = (b8*)smem;                                       // [24][64] operand images of the current super-block
-  char* Xw = smem + HB_BYTES + wave * C::XBYTES;            // this wave's transpose image, 3 planes [32 rows][XRS]
-  float* park = (float*)(smem + HB_BYTES + NW * C::XBYTES); // [NW][32][ES] parked d_out tiles
+  // [2][24][64] operand images of the current and the next super-block (filled by LDS-DMA one super-block ahead)
+  char* Xw = smem + 2 * HB_BYTES + wave * C::XBYTES;            // this wave's transpose image, 3 planes [32 rows][XRS]
+  float* park = (float*)(smem + 2 * HB_BYTES + NW * C::XBYTES); // [NW][32][ES] parked d_out tiles
   float* Pw = park + wave * C::PARK_FLOATS;
 
+#ifdef ACATTN_CE_STAMPS
+  unsigned long long cyc_[8] = {}, last_ = 0;
+#endif
+  CE6_STAMP(-1);
   // ---- the wave's table rows, split, in both operand orders -------------------------------------------------------
   b8 Er[TILES][2][3];
 #pragma unroll
@@ -147,16 +176,14 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
     const int item = item0 + 16 * t + c;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-      if (item < N) {
-        v0 = *(const f4*)(P.table + (size_t)item * CH + 32 * s + 8 * g);
-        v1 = *(const f4*)(P.table + (size_t)item * CH + 32 * s + 8 * g + 4);
-      }
+      // (clamped address + select: a branch per load would serialise the prologue's 100+ requests)
+      const float* src = P.table + (size_t)min(item, N - 1) * CH + 32 * s + 8 * g;
+      const f4 v0 = *(const f4*)src, v1 = *(const f4*)(src + 4);
       float x[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        x[j] = v0[j];
-        x[4 + j] = v1[j];
+        x[j] = item < N ? v0[j] : 0.f;
+        x[4 + j] = item < N ? v1[j] : 0.f;
       }
       split8(x, Er[t][s][0], Er[t][s][1], Er[t][s][2]);
     }
@@ -170,7 +197,8 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int item = item0 + 16 * (2 * u + (j >> 2)) + 4 * g + (j & 3);
-        x[j] = item < N ? P.table[(size_t)item * CH + 16 * cb + c] : 0.f;
+        const float v = P.table[(size_t)min(item, N - 1) * CH + 16 * cb + c];
+        x[j] = item < N ? v : 0.f;
       }
       split8(x, Ec[u][cb][0], Ec[u][cb][1], Ec[u][cb][2]);
     }
@@ -182,14 +210,17 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
     for (int cb = 0; cb < 4; ++cb) dE[t][cb] = f4{0.f, 0.f, 0.f, 0.f};
 
   const int nsb = (B + 31) >> 5;
-  constexpr int HV = HB_BYTES / 16 / (64 * NW);  // 16-byte pieces of a super-block's images per thread (6)
-  f4 h_next[HV];
+  // A super-block's images go global -> LDS by DMA, each wave a quarter (six 1-KB pieces), one super-block ahead; the
+  // rows' lse / coef / target are fetched into registers one super-block ahead.
+  auto dma_rows = [&](int sb) {
+    const char* src = (const char*)Hb + (size_t)sb * HB_BYTES + (6 * wave) * 1024 + lane * 16;
+    char* dst = smem + (sb & 1) * HB_BYTES + (6 * wave) * 1024;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) dma16(src + u * 1024, dst + u * 1024);
+  };
   float lse_next[2] = {0.f, 0.f}, cf_next[2] = {0.f, 0.f};
   int tgt_next[2] = {-1, -1};
   auto prefetch = [&](int sb) {
-    const f4* src = (const f4*)Hb + (size_t)sb * (HB_BYTES / 16);
-#pragma unroll
-    for (int u = 0; u < HV; ++u) h_next[u] = src[threadIdx.x + u * 64 * NW];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int row = 32 * sb + 16 * h + c;
@@ -199,26 +230,27 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
       tgt_next[h] = ok ? (int)P.target[row] : -1;
     }
   };
-  auto stage = [&]() {
-#pragma unroll
-    for (int u = 0; u < HV; ++u) ((f4*)Hs)[threadIdx.x + u * 64 * NW] = h_next[u];
-  };
+  dma_rows(0);
   prefetch(0);
-  stage();
   float l2_cur[2], cf_cur[2];
   int tgt_cur[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    l2_cur[h] = lse_next[h] * kLog2e;
-    cf_cur[h] = cf_next[h];
-    tgt_cur[h] = tgt_next[h];
-  }
-  if (nsb > 1) prefetch(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  CE6_STAMP(6);
   for (int sb = 0; sb < nsb; ++sb) {
+    const b8* Hs = (const b8*)(smem + (sb & 1) * HB_BYTES);
+    if (sb + 1 < nsb) dma_rows(sb + 1);  // its buffer was last read before the previous super-block's first barrier
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      l2_cur[h] = lse_next[h] * kLog2e;
+      cf_cur[h] = cf_next[h];
+      tgt_cur[h] = tgt_next[h];
+    }
+    if (sb + 1 < nsb) prefetch(sb + 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      CE6_STAMP(-1);
       const bool row_ok = 32 * sb + 16 * h + c < B;
       // ---- P1: logits^T of the wave's items for the half's 16 rows -------------------------------------------------
       b8 Hr[2][3];
@@ -234,6 +266,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
       _Pragma("unroll") for (int t = 0; t < TILES; ++t) dl[t] = mfma_bf(Er[t][s][p], Hr[s][q], dl[t]);
       CE6_TERMS(CE6_P1)
 #undef CE6_P1
+      CE6_STAMP(0);
       // ---- soft-max arithmetic (acattn_ce.hip's, the layout is the same) -------------------------------------------
       if (ragged) {
 #pragma unroll
@@ -275,6 +308,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
           dl[t] = x * cf;
         }
       }
+      CE6_STAMP(1);
       // ---- split dl; its planes are P2's B operand as they stand, and go to the transpose image for P3 -------------
       b8 dlB[C::UP][3];
 #pragma unroll
@@ -297,6 +331,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
             *(b4*)(dst + 32) = __builtin_shufflevector(dlB[u][p], dlB[u][p], 4, 5, 6, 7);  // items 16(2u + 1) + 4g ..
           }
       }
+      CE6_STAMP(2);
       // ---- P2: d out^T (this wave's items) = E^T . dl^T -------------------------------------------------------------
       f4 dh[4];
 #pragma unroll
@@ -313,6 +348,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         Pw[(16 * h + c) * ES + CH] = m_w;
         Pw[(16 * h + c) * ES + CH + 1] = s_w;
       }
+      CE6_STAMP(3);
     }
     if (WITH_TABLE_GRAD) {
       // ---- P3: d E (this wave's items) += dl^T . out over the super-block's 32 rows --------------------------------
@@ -340,18 +376,10 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
 #undef CE6_P3
       }
     }
-    __syncthreads();  // every wave's tiles are parked; nobody reads the operand images any more
-    // next super-block's images, then the fold of this one's d_out tiles (each thread sums float4s of the four waves)
-    if (sb + 1 < nsb) {
-      stage();
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        l2_cur[h] = lse_next[h] * kLog2e;
-        cf_cur[h] = cf_next[h];
-        tgt_cur[h] = tgt_next[h];
-      }
-      if (sb + 2 < nsb) prefetch(sb + 2);
-    }
+    CE6_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next super-block's images has landed
+    __syncthreads();  // every wave's tiles are parked, the next images are complete
+    // the fold of this super-block's d_out tiles (each thread sums float4s of the four waves)
     for (int idx = threadIdx.x; idx < 32 * (CH / 4); idx += 64 * NW) {
       const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
       if (32 * sb + r < B) {
@@ -380,7 +408,8 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         *(f4*)(d_out_slab + (size_t)blockIdx.x * B * CH + o) = sum;
       }
     }
-    __syncthreads();  // the images are staged, the parked tiles are free
+    __syncthreads();  // the parked tiles are free
+    CE6_STAMP(5);
   }
   if (WITH_TABLE_GRAD) {
 #pragma unroll
@@ -551,6 +580,11 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
       }
     }
   }
+  CE6_STAMP(7);
+#ifdef ACATTN_CE_STAMPS
+  if (lane == 0 && blockIdx.x * NW + wave < 4096)
+    for (int k = 0; k < 8; ++k) g_ce6_stamps[(blockIdx.x * NW + wave) * 8 + k] = cyc_[k];
+#endif
 }
 
 template <class K>
@@ -585,3 +619,9 @@ int acattn_launch_ce6_sweep(const acattn_ce_problem& p, const float* lse, const 
   }
   return (int)hipGetLastError();
 }
+
+#ifdef ACATTN_CE_STAMPS
+extern "C" int acattn_debug_ce6_stamps(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ce6_stamps), (size_t)n_words * 8);
+}
+#endif
