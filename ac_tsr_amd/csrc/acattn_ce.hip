@@ -1004,7 +1004,7 @@ int64_t ws_bytes_base(const acattn_ce_problem& p) {
   if constexpr (CH == 64) {
     const int64_t n_wg6 = (p.N + CE_NW * 96 - 1) / (CE_NW * 96);
     const int64_t b6 = n_wg6 * p.B * (CH * (int64_t)sizeof(float) + (int64_t)sizeof(float2));
-    six = b6 <= kSlabLimit ? b6 : 0;
+    six = std::max(b6 <= kSlabLimit ? b6 : 0, (n_wg6 * 8 + 256) * p.B * (int64_t)sizeof(float2));  // (forward: eight waves' partials per workgroup + leftover tiles')
   }
   if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
@@ -1037,6 +1037,16 @@ int64_t ws_bytes_base(const acattn_ce_problem& p) {
 
 template <int CH>
 int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss, hipStream_t stream) {
+  if constexpr (CH == 64) {
+    int n_wg, n_left;
+    if (ce6_plan<CH>(p.N, n_wg, n_left)) {
+      void* rows_ws = (char*)ws + align256(ws_bytes_base<CH>(p));
+      if (const int e = acattn_launch_ce6_fwd_sweep(p, (float2*)ws, rows_ws, n_wg, n_left, stream)) return e;
+      hipLaunchKernelGGL((ce_fwd_reduce_kernel<CH>), dim3((p.B + 3) / 4), dim3(256), 0, stream, p, (const float2*)ws,
+                         n_wg * 8 + n_left, lse, row_loss);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (CH == 64 || CH == 128) {
     int n_wg, n_left;
     if (split_plan<CH>(p.N, n_wg, n_left)) {
@@ -1068,9 +1078,7 @@ int launch_bwd(const acattn_ce_problem& p, const float* lse, const float* coef, 
       float* slab = (float*)ws;
       void* rows_ws = (char*)ws + align256(ws_bytes_base<CH>(p));
       if (const int e = acattn_launch_ce6_sweep(p, lse, coef, slab, d_table, nullptr, rows_ws, n_wg, n_left, false, stream)) return e;
-      hipLaunchKernelGGL(ce_bwd_reduce_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, stream, slab, n_wg + n_left,
-                         n_out, d_out);
-      return (int)hipGetLastError();
+      return acattn_launch_ce6_onehot_reduce(p, coef, slab, n_wg + n_left, d_out, d_table, stream);
     }
   }
   if constexpr (CH == 64 || CH == 128) {

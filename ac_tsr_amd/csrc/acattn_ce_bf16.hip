@@ -219,7 +219,6 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
     for (int u = 0; u < 6; ++u) dma16(src + u * 1024, dst + u * 1024);
   };
   float lse_next[2] = {0.f, 0.f}, cf_next[2] = {0.f, 0.f};
-  int tgt_next[2] = {-1, -1};
   auto prefetch = [&](int sb) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -227,13 +226,11 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
       const bool ok = row < B;
       lse_next[h] = (ok && !DIR) ? lse[row] : 0.f;
       cf_next[h] = (ok && !DIR) ? coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f) : 0.f;
-      tgt_next[h] = ok ? (int)P.target[row] : -1;
     }
   };
   dma_rows(0);
   prefetch(0);
   float l2_cur[2], cf_cur[2];
-  int tgt_cur[2];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -245,7 +242,6 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
     for (int h = 0; h < 2; ++h) {
       l2_cur[h] = lse_next[h] * kLog2e;
       cf_cur[h] = cf_next[h];
-      tgt_cur[h] = tgt_next[h];
     }
     if (sb + 1 < nsb) prefetch(sb + 1);
 #pragma unroll
@@ -292,19 +288,14 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         }
         s_w = quad_sum((sv[0] + sv[1]) + (sv[2] + sv[3]));
       } else {
-        const int tgt = row_ok ? tgt_cur[h] - item0 : -1;  // target as an index into this wave's items
-        const int t_t = tgt >> 4, g_t = (tgt >> 2) & 3, r_t = tgt & 3;
-        const bool mine = tgt >= 0 && tgt < C::ITEMS && g_t == g;
+        // dl = coef * softmax.  The target's one-hot is not subtracted here: its two contributions, -coef E_target to the
+        // row's d_out and -coef out_row to d_table[target], are added by ce6_onehot_reduce_kernel behind the sweep.
         const float l2 = l2_cur[h], cf = cf_cur[h];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           f4 x = dl[t] * kLog2e - l2;
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
-          if (mine && t == t_t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] -= (r == r_t) ? 1.0f : 0.0f;
-          }
           dl[t] = x * cf;
         }
       }
@@ -424,152 +415,161 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
       }
   }
   if (n_left > 0) {
-    // Leftover units (tile, 16-row block) behind the whole rounds, exactly acattn_ce.hip's scheme and arithmetic (exact
-    // fp32 MFMA: a quarter sweep of one tile per wave at most).  Results: slab / partial number gridDim.x + tile.
-    constexpr int KS = CH / 4, DT = CH / 16;
-    const int nrb = (B + 15) >> 4;
+    // Leftover tiles behind the whole rounds (acattn_ce.hip's scheme): a UNIT is (leftover tile, super-block).  With a
+    // table gradient workgroup l < n_left takes all of tile l, its waves every fourth super-block, so that the tile's
+    // d_table rows are summed inside the workgroup; without one the units are dealt out evenly over all waves.  Same
+    // three products on one item tile (P2's K = 32 half empty); every wave works on its own, its operand images come
+    // straight from global memory (L2) one unit ahead -- the table operands' registers are free now.
+    // Results: slab / partial number gridDim.x + tile.
     const int wid = blockIdx.x * NW + wave;
     int first, stride, n_my;
     if (WITH_TABLE_GRAD) {
-      first = blockIdx.x * nrb + wave;
+      first = blockIdx.x * nsb + wave;
       stride = NW;
-      n_my = (int)blockIdx.x < n_left ? (nrb - wave + NW - 1) / NW : 0;
+      n_my = (int)blockIdx.x < n_left ? (nsb - wave + NW - 1) / NW : 0;
     } else {
-      const int n_units = n_left * nrb, U = (n_units + gridDim.x * NW - 1) / (gridDim.x * NW);
+      const int n_units = n_left * nsb, U = (n_units + gridDim.x * NW - 1) / (gridDim.x * NW);
       first = wid * U;
       stride = 1;
       n_my = min(max(n_units - first, 0), U);
     }
-    constexpr int TSX = 48;  // 16 * odd
-    float* Ex = (float*)Xw;       // [16][ES] the leftover tile's table rows
-    float* Hx = Ex + 16 * ES;     // [16][ES] this wave's batch rows
-    float* Xx = Hx + 16 * ES;     // [16][TSX] transpose scratch
-    f4 dEx[DT];
+    constexpr int XRS1 = 40, XPL1 = 32 * XRS1;  // one-tile transpose image: 16 items + pad per batch row
+    b8 Er1[2][3], Ec1[4][3];
+    f4 dE1[4];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dEx[dt] = f4{0.f, 0.f, 0.f, 0.f};
-    constexpr int HX = 16 * (CH / 4) / 64;
-    constexpr int GU = 4;
-    f4 hx_g[GU][HX];
-    float lse_g[GU], cf_g[GU];
-    int tgt_g[GU];
-    auto prefetch_x = [&](int q, int rb) {
+    for (int cb = 0; cb < 4; ++cb) dE1[cb] = f4{0.f, 0.f, 0.f, 0.f};
+    b8 Hn[HSLOTS];
+    float lse_n[2] = {0.f, 0.f}, cf_n[2] = {0.f, 0.f};
+    auto fetch = [&](int u) {
+      const int sb = u % nsb;
+      const b8* src = Hb + (size_t)sb * HSLOTS * 64 + lane;
 #pragma unroll
-      for (int u = 0; u < HX; ++u) {
-        const int idx = lane + 64 * u;
-        const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
-        hx_g[q][u] = f4{0.f, 0.f, 0.f, 0.f};
-        if (16 * rb + r < B) hx_g[q][u] = *(const f4*)(P.out + (size_t)(16 * rb + r) * CH + 4 * c4);
-      }
-      const int row = 16 * rb + c;
-      const bool ok = row < B;
-      lse_g[q] = (ok && !DIR) ? lse[row] : 0.f;
-      cf_g[q] = (ok && !DIR) ? coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f) : 0.f;
-      tgt_g[q] = ok ? (int)P.target[row] : -1;
-    };
-    int cur_tile = -1;
-    for (int k0 = 0; k0 < n_my; k0 += GU) {
+      for (int k = 0; k < HSLOTS; ++k) Hn[k] = src[k * 64];
 #pragma unroll
-      for (int q = 0; q < GU; ++q)
-        if (k0 + q < n_my) prefetch_x(q, (first + (k0 + q) * stride) % nrb);
-#pragma unroll
-      for (int q = 0; q < GU; ++q) {
-        if (k0 + q >= n_my) break;
-        const int u = first + (k0 + q) * stride, tile = u / nrb, rb = u - tile * nrb;
-        const int itx = gridDim.x * NW * C::ITEMS + 16 * tile;
-        const size_t vslab = (size_t)(gridDim.x + tile) * B;
-        if (tile != cur_tile) {  // (uniform per wave)
-          cur_tile = tile;
-          for (int idx = lane; idx < 16 * (CH / 4); idx += 64) {
-            const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if (itx + r < N) v = *(const f4*)(P.table + (size_t)(itx + r) * CH + 4 * c4);
-            *(f4*)(Ex + r * ES + 4 * c4) = v;
-          }
-        }
-#pragma unroll
-        for (int w = 0; w < HX; ++w) {
-          const int idx = lane + 64 * w;
-          const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
-          *(f4*)(Hx + r * ES + 4 * c4) = hx_g[q][w];
-        }
-        const int row = 16 * rb + c;
+      for (int h = 0; h < 2; ++h) {
+        const int row = 32 * sb + 16 * h + c;
         const bool ok = row < B;
-        const float l2 = lse_g[q] * kLog2e;
-        const float cf = cf_g[q];
-        const int tgt = ok ? tgt_g[q] - itx : -1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float hf[KS];
+        lse_n[h] = (ok && !DIR) ? lse[row] : 0.f;
+        cf_n[h] = (ok && !DIR) ? coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f) : 0.f;
+      }
+    };
+    if (n_my > 0) fetch(first);
+    int cur_tile = -1;
+    for (int k = 0; k < n_my; ++k) {
+      const int u = first + k * stride, tile = u / nsb, sb = u - tile * nsb;
+      const int itx = gridDim.x * NW * C::ITEMS + 16 * tile;  // first item of the leftover tile
+      const size_t vslab = (size_t)(gridDim.x + tile) * B;    // row offset of this tile's slab / partials
+      if (tile != cur_tile) {  // (uniform per wave)
+        cur_tile = tile;
 #pragma unroll
-        for (int s4 = 0; s4 < KS / 4; ++s4) {
-          const f4 v = *(const f4*)(Hx + c * ES + KS * g + 4 * s4);
+        for (int s = 0; s < 2; ++s) {
+          const float* src = P.table + (size_t)min(itx + c, N - 1) * CH + 32 * s + 8 * g;
+          const f4 v0 = *(const f4*)src, v1 = *(const f4*)(src + 4);
+          float x[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hf[4 * s4 + e] = v[e];
+          for (int j = 0; j < 4; ++j) {
+            x[j] = itx + c < N ? v0[j] : 0.f;
+            x[4 + j] = itx + c < N ? v1[j] : 0.f;
+          }
+          split8(x, Er1[s][0], Er1[s][1], Er1[s][2]);
         }
-        f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
-        for (int s4 = 0; s4 < KS / 4; ++s4) {
-          const f4 e4 = *(const f4*)(Ex + c * ES + KS * g + 4 * s4);
-          a0 = mfma16(e4[0], hf[4 * s4 + 0], a0);
-          a1 = mfma16(e4[1], hf[4 * s4 + 1], a1);
-          a0 = mfma16(e4[2], hf[4 * s4 + 2], a0);
-          a1 = mfma16(e4[3], hf[4 * s4 + 3], a1);
+        for (int cb = 0; cb < 4; ++cb) {
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int item = itx + 4 * g + j;
+            const float v = P.table[(size_t)min(item, N - 1) * CH + 16 * cb + c];
+            x[j] = item < N ? v : 0.f;
+            x[4 + j] = 0.f;
+          }
+          split8(x, Ec1[cb][0], Ec1[cb][1], Ec1[cb][2]);
         }
-        f4 dlx = a0 + a1;
+      }
+      b8 Hq[HSLOTS];
+#pragma unroll
+      for (int i = 0; i < HSLOTS; ++i) Hq[i] = Hn[i];
+      float l2_u[2], cf_u[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        l2_u[h] = lse_n[h] * kLog2e;
+        cf_u[h] = cf_n[h];
+      }
+      if (k + 1 < n_my) fetch(first + (k + 1) * stride);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = 32 * sb + 16 * h + c;
+        f4 a = {0.f, 0.f, 0.f, 0.f};
+#define CE6_L1(p, q) \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) a = mfma_bf(Er1[s][p], Hq[(2 * h + s) * 3 + q], a);
+        CE6_TERMS(CE6_L1)
+#undef CE6_L1
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (itx + 4 * g + r >= N) dlx[r] = ACATTN_NEG_INF;
+          if (itx + 4 * g + r >= N) a[r] = ACATTN_NEG_INF;
         float m_w = ACATTN_NEG_INF, s_w = 0.f;
         if (DIR) {
-          m_w = quad_max(fmaxf(fmaxf(dlx[0], dlx[1]), fmaxf(dlx[2], dlx[3])));
+          m_w = quad_max(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
           const float m2 = m_w > ACATTN_NEG_INF ? m_w * kLog2e : 0.f;
-          f4 x = dlx * kLog2e - m2;
+          f4 x = a * kLog2e - m2;
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
-          dlx = x;
+          a = x;
           s_w = quad_sum((x[0] + x[1]) + (x[2] + x[3]));
         } else {
-          f4 x = dlx * kLog2e - l2;
+          f4 x = a * kLog2e - l2_u[h];
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
-          if (tgt >= 0 && tgt < 16 && ((tgt >> 2) & 3) == g) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] -= (r == (tgt & 3)) ? 1.0f : 0.0f;
-          }
-          dlx = x * cf;
+          a = x * cf_u[h];
         }
-        f4 dh[DT];
+        float x8[8];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) dh[dt] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const float* ep = Ex + (4 * g + kk) * ES + c;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) dh[dt] = mfma16(ep[16 * dt], dlx[kk], dh[dt]);
+        for (int r = 0; r < 4; ++r) {
+          x8[r] = a[r];
+          x8[4 + r] = 0.f;
         }
-        if (ok) {
+        b8 dlB1[3];
+        split8(x8, dlB1[0], dlB1[1], dlB1[2]);
+        if (WITH_TABLE_GRAD) {
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) *(f4*)(d_out_slab + (vslab + row) * CH + 16 * dt + 4 * g) = dh[dt];
+          for (int p = 0; p < 3; ++p)
+            *(b4*)(Xw + p * XPL1 + (16 * h + c) * XRS1 + 8 * g) = __builtin_shufflevector(dlB1[p], dlB1[p], 0, 1, 2, 3);
+        }
+        f4 dh[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) dh[cb] = f4{0.f, 0.f, 0.f, 0.f};
+#define CE6_L2(p, q) \
+  _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) dh[cb] = mfma_bf(Ec1[cb][p], dlB1[q], dh[cb]);
+        CE6_TERMS(CE6_L2)
+#undef CE6_L2
+        if (row < B) {
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) *(f4*)(d_out_slab + (vslab + row) * CH + 16 * cb + 4 * g) = dh[cb];
           if (DIR && g == 0) part[vslab + row] = float2{m_w, s_w};
         }
-        if (WITH_TABLE_GRAD) {
-          *(f4*)(Xx + c * TSX + 4 * g) = dlx;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      if (WITH_TABLE_GRAD) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        b8 At[3];
 #pragma unroll
-          for (int sr = 0; sr < 4; ++sr) {
-            const float at = Xx[(4 * sr + g) * TSX + c];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) dEx[dt] = mfma16(at, Hx[(4 * sr + g) * ES + 16 * dt + c], dEx[dt]);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int p = 0; p < 3; ++p) {
+          const char* src = Xw + p * XPL1 + (8 * g + (c >> 2)) * XRS1 + 8 * (c & 3);
+          const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(src));
+          const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(src + 4 * XRS1));
+          At[p] = __builtin_bit_cast(b8, (s8v)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
+#define CE6_L3(p, q) \
+  _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) dE1[cb] = mfma_bf(At[p], Hq[12 + 4 * q + cb], dE1[cb]);
+        CE6_TERMS(CE6_L3)
+#undef CE6_L3
       }
     }
     if (WITH_TABLE_GRAD && (int)blockIdx.x < n_left) {  // the four waves' shares of the tile's d_table rows meet in the parked-tile areas
       const int itx = gridDim.x * NW * C::ITEMS + 16 * blockIdx.x;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+      for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Pw[(4 * g + r) * ES + 16 * dt + c] = dEx[dt][r];
+        for (int r = 0; r < 4; ++r) Pw[(4 * g + r) * ES + 16 * cb + c] = dE1[cb][r];
       __syncthreads();
       for (int idx = threadIdx.x; idx < 16 * CH; idx += 64 * NW) {
         const int i = idx / CH, hcol = idx - i * CH;
@@ -585,6 +585,202 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
   if (lane == 0 && blockIdx.x * NW + wave < 4096)
     for (int k = 0; k < 8; ++k) g_ce6_stamps[(blockIdx.x * NW + wave) * 8 + k] = cyc_[k];
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: per (row, wave) partial (max, sum exp) of the wave's items (ce_fwd_reduce_kernel of acattn_ce.hip folds them)
+// ---------------------------------------------------------------------------------------------------------
+// P1 alone.  EIGHT waves of three tiles per workgroup (the same 384 items as the backward's four waves of six): the table
+// operands are 72 registers, two waves share a SIMD and one's soft-max arithmetic runs under the other's MFMAs.  The
+// rows' images (the 12 by-row slots) come by LDS-DMA into a double buffer, one barrier per super-block.
+constexpr int NWF = 8;
+constexpr int FT = 3;
+constexpr int HR_BYTES = 12 * 64 * 16;
+
+__global__ void __launch_bounds__(64 * NWF) ce6_fwd_kernel(const acattn_ce_problem P, float2* __restrict__ part,
+                                                           const b8* __restrict__ Hb, const int n_left) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int wid = blockIdx.x * NWF + wave;
+  const int item0 = wid * 16 * FT;
+  const int B = P.B, N = P.N;
+  const bool ragged = item0 + 16 * FT > N;  // (uniform per wave)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][12][64] x 16 bytes
+
+  b8 Er[FT][2][3];
+#pragma unroll
+  for (int t = 0; t < FT; ++t) {
+    const int item = item0 + 16 * t + c;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float* src = P.table + (size_t)min(item, N - 1) * CH + 32 * s + 8 * g;
+      const f4 v0 = *(const f4*)src, v1 = *(const f4*)(src + 4);
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = item < N ? v0[j] : 0.f;
+        x[4 + j] = item < N ? v1[j] : 0.f;
+      }
+      split8(x, Er[t][s][0], Er[t][s][1], Er[t][s][2]);
+    }
+  }
+  const int nsb = (B + 31) >> 5;
+  auto dma_rows = [&](int sb) {  // waves 0..5 two slots each
+    if (wave < 6) {
+      const char* src = (const char*)Hb + (size_t)sb * HB_BYTES + (2 * wave) * 1024 + lane * 16;
+      char* dst = smem + (sb & 1) * HR_BYTES + (2 * wave) * 1024;
+      dma16(src, dst);
+      dma16(src + 1024, dst + 1024);
+    }
+  };
+  dma_rows(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int sb = 0; sb < nsb; ++sb) {
+    const b8* Hs = (const b8*)(smem + (sb & 1) * HR_BYTES);
+    if (sb + 1 < nsb) dma_rows(sb + 1);  // its buffer was last read before the previous super-block's barrier
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      b8 Hr[2][3];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Hr[s][q] = Hs[((2 * h + s) * 3 + q) * 64 + lane];
+      f4 acc[FT];
+#pragma unroll
+      for (int t = 0; t < FT; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+#define CE6_F1(p, q)                             \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) \
+      _Pragma("unroll") for (int t = 0; t < FT; ++t) acc[t] = mfma_bf(Er[t][s][p], Hr[s][q], acc[t]);
+      CE6_TERMS(CE6_F1)
+#undef CE6_F1
+      if (ragged) {
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (item0 + 16 * t + 4 * g + r >= N) acc[t][r] = ACATTN_NEG_INF;
+      }
+      float m = ACATTN_NEG_INF;
+#pragma unroll
+      for (int t = 0; t < FT; ++t) m = fmaxf(fmaxf(fmaxf(fmaxf(m, acc[t][0]), acc[t][1]), acc[t][2]), acc[t][3]);
+      m = quad_max(m);
+      float sum = 0.f;
+      if (m > ACATTN_NEG_INF) {
+        const float m2 = m * kLog2e;
+        f4 sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < FT; ++t) {
+          f4 x = acc[t] * kLog2e - m2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+          sv += x;
+        }
+        sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+      }
+      sum = quad_sum(sum);
+      const int row = 32 * sb + 16 * h + c;
+      if (g == 0 && row < B) part[(size_t)wid * B + row] = float2{m, sum};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (n_left > 0) {
+    // leftover units (tile, super-block), n_left * nsb of them, dealt out evenly: wave w takes units [w U, (w + 1) U);
+    // operand images straight from global memory.  Partial number gridDim.x * NWF + tile.
+    const int n_units = n_left * nsb, U = (n_units + gridDim.x * NWF - 1) / (gridDim.x * NWF);
+    const int first = wid * U, n_my = min(max(n_units - first, 0), U);
+    int cur_tile = -1;
+    b8 Er1[2][3];
+    for (int k = 0; k < n_my; ++k) {
+      const int u = first + k, tile = u / nsb, sb = u - tile * nsb;
+      const int itx = gridDim.x * NWF * 16 * FT + 16 * tile;
+      b8 Hq[12];
+      const b8* src = Hb + (size_t)sb * HSLOTS * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Hq[i] = src[i * 64];
+      if (tile != cur_tile) {  // (uniform per wave)
+        cur_tile = tile;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const float* tsrc = P.table + (size_t)min(itx + c, N - 1) * CH + 32 * s + 8 * g;
+          const f4 v0 = *(const f4*)tsrc, v1 = *(const f4*)(tsrc + 4);
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            x[j] = itx + c < N ? v0[j] : 0.f;
+            x[4 + j] = itx + c < N ? v1[j] : 0.f;
+          }
+          split8(x, Er1[s][0], Er1[s][1], Er1[s][2]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#define CE6_FL(p, q)                                          \
+  a0 = mfma_bf(Er1[0][p], Hq[(2 * h + 0) * 3 + q], a0);      \
+  a1 = mfma_bf(Er1[1][p], Hq[(2 * h + 1) * 3 + q], a1);
+        CE6_TERMS(CE6_FL)
+#undef CE6_FL
+        f4 a = a0 + a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (itx + 4 * g + r >= N) a[r] = ACATTN_NEG_INF;
+        const float m = quad_max(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+        float sum = 0.f;
+        if (m > ACATTN_NEG_INF) {
+          f4 x = a * kLog2e - m * kLog2e;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = __builtin_amdgcn_exp2f(x[r]);
+          sum = (x[0] + x[1]) + (x[2] + x[3]);
+        }
+        sum = quad_sum(sum);
+        const int row = 32 * sb + 16 * h + c;
+        if (g == 0 && row < B) part[(size_t)(gridDim.x * NWF + tile) * B + row] = float2{m, sum};
+      }
+    }
+  }
+}
+
+// d_out[i] = sum over workgroups of slab[wg][i] (acattn_ce.hip's ce_bwd_reduce_kernel: 32 outputs per workgroup, 8 threads
+// per output) - coef_row E_target(row)[ch], and d_table[target(row)][ch] -= coef_row out[row][ch]: the one-hot part of
+// dl = coef (softmax - onehot), which the sweep leaves out.  d_table's rows were written by the sweep in front of this
+// launch; several rows may share a target, hence atomics (B x 64 of them).
+__global__ void __launch_bounds__(256) ce6_onehot_reduce_kernel(const acattn_ce_problem P, const float* __restrict__ coef,
+                                                                 const float* __restrict__ slab, const int n_slabs,
+                                                                 float* __restrict__ d_out, float* __restrict__ d_table) {
+  const int sl = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int64_t n_out = (int64_t)P.B * CH;
+  const int64_t i = (int64_t)blockIdx.x * 32 + sl;
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  if (i < n_out) {
+    const float* ps = slab + i;
+    int p = q;
+    for (; p + 56 < n_slabs; p += 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += ps[(size_t)(p + 8 * u) * n_out];
+    }
+    for (; p < n_slabs; p += 8) a[0] += ps[(size_t)p * n_out];
+  }
+  __shared__ float red[8][32];
+  red[q][sl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (q == 0 && i < n_out) {
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += red[u][sl];
+    const int row = (int)(i / CH), ch = (int)(i - (int64_t)row * CH);
+    const long long tgt = P.target[row];
+    if (tgt >= 0 && tgt < P.N) {  // (an invalid target: the row's loss is NaN already, see ce_fwd_reduce_kernel)
+      const float cf = coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f);
+      v -= cf * P.table[(size_t)tgt * CH + ch];
+      if (d_table) atomicAdd(d_table + (size_t)tgt * CH + ch, -cf * P.out[i]);
+    }
+    d_out[i] = v;
+  }
 }
 
 template <class K>
@@ -625,3 +821,19 @@ extern "C" int acattn_debug_ce6_stamps(unsigned long long* host, int n_words) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ce6_stamps), (size_t)n_words * 8);
 }
 #endif
+
+int acattn_launch_ce6_onehot_reduce(const acattn_ce_problem& p, const float* coef, const float* slab, int n_slabs, float* d_out,
+                                    float* d_table, hipStream_t stream) {
+  const int64_t n_out = (int64_t)p.B * CH;
+  hipLaunchKernelGGL(ce6_onehot_reduce_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, stream, p, coef, slab, n_slabs,
+                     d_out, d_table);
+  return (int)hipGetLastError();
+}
+
+// Forward partials: (n_wg * 8 + n_left) x B (max, sum-exp) pairs in `part`.
+int acattn_launch_ce6_fwd_sweep(const acattn_ce_problem& p, float2* part, void* rows_ws, int n_wg, int n_left, hipStream_t stream) {
+  b8* Hb = (b8*)rows_ws;
+  hipLaunchKernelGGL(ce_split_rows_kernel, dim3((p.B + 31) / 32), dim3(256), 0, stream, p.out, p.B, Hb);
+  hipLaunchKernelGGL(ce6_fwd_kernel, dim3(n_wg), dim3(64 * NWF), 2 * HR_BYTES, stream, p, part, (const b8*)Hb, n_left);
+  return (int)hipGetLastError();
+}

@@ -380,6 +380,9 @@ int acattn_launch_zero(float* p, size_t n, hipStream_t stream);
 int64_t acattn_ce6_rows_bytes(const acattn_ce_problem& p);
 int acattn_launch_ce6_sweep(const acattn_ce_problem& p, const float* lse, const float* coef, float* slab, float* d_table,
                             float2* part, void* rows_ws, int n_wg, int n_left, bool dir, hipStream_t stream);
+int acattn_launch_ce6_onehot_reduce(const acattn_ce_problem& p, const float* coef, const float* slab, int n_slabs, float* d_out,
+                                    float* d_table, hipStream_t stream);
+int acattn_launch_ce6_fwd_sweep(const acattn_ce_problem& p, float2* part, void* rows_ws, int n_wg, int n_left, hipStream_t stream);
 int acattn_ce_products_choice(int mode);
 int acattn_launch_dense_ce_fwd(const float* logits, int64_t rows, int64_t N, const int64_t* target, float* lse, float* row_loss,
                                hipStream_t stream);
