@@ -1043,7 +1043,7 @@ int launch_fwd(const acattn_ce_problem& p, void* ws, float* lse, float* row_loss
       void* rows_ws = (char*)ws + align256(ws_bytes_base<CH>(p));
       if (const int e = acattn_launch_ce6_fwd_sweep(p, (float2*)ws, rows_ws, n_wg, n_left, stream)) return e;
       hipLaunchKernelGGL((ce_fwd_reduce_kernel<CH>), dim3((p.B + 3) / 4), dim3(256), 0, stream, p, (const float2*)ws,
-                         n_wg * 8 + n_left, lse, row_loss);
+                         n_wg + n_left, lse, row_loss);
       return (int)hipGetLastError();
     }
   }

@@ -606,8 +606,12 @@ __global__ void __launch_bounds__(64 * NWF) ce6_fwd_kernel(const acattn_ce_probl
   const int item0 = wid * 16 * FT;
   const int B = P.B, N = P.N;
   const bool ragged = item0 + 16 * FT > N;  // (uniform per wave)
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][12][64] x 16 bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][12][64] x 16 bytes, then the fold area
 
+#ifdef ACATTN_CE_STAMPS
+  unsigned long long cyc_[8] = {}, last_ = 0;
+#endif
+  CE6_STAMP(-1);
   b8 Er[FT][2][3];
 #pragma unroll
   for (int t = 0; t < FT; ++t) {
@@ -637,9 +641,39 @@ __global__ void __launch_bounds__(64 * NWF) ce6_fwd_kernel(const acattn_ce_probl
   dma_rows(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // Waves w and w + 4 share a SIMD and leave every barrier in step: both would want the matrix pipe, then both the vector
+  // pipe.  With different priorities one runs ahead by a phase and each one's soft-max arithmetic falls under the other's
+  // MFMAs.
+  static_assert(NWF == 8, "two waves per SIMD");
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  // The eight waves' (max, sum-exp) pairs of a super-block's 32 rows meet in LDS ([2][NWF][32] pairs, by super-block
+  // parity) and are folded by the first 32 threads at the top of the NEXT iteration, behind the barrier that ends this
+  // one: one partial per (workgroup, row) leaves the kernel, and the wait in front of the barrier (for the DMA) does not
+  // sit behind stores.
+  float2* fold = (float2*)(smem + 2 * HR_BYTES);
+  auto store_res = [&](int sb) {
+    if (threadIdx.x < 32) {
+      const float2* f = fold + (sb & 1) * NWF * 32 + threadIdx.x;
+      float2 v[NWF];
+      float m = ACATTN_NEG_INF;
+#pragma unroll
+      for (int w = 0; w < NWF; ++w) {
+        v[w] = f[w * 32];
+        m = fmaxf(m, v[w].x);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWF; ++w)
+        sum += v[w].x > ACATTN_NEG_INF ? v[w].y * __builtin_amdgcn_exp2f((v[w].x - m) * kLog2e) : 0.f;
+      const int row = 32 * sb + threadIdx.x;
+      if (row < B) part[(size_t)blockIdx.x * B + row] = float2{m, sum};
+    }
+  };
   for (int sb = 0; sb < nsb; ++sb) {
     const b8* Hs = (const b8*)(smem + (sb & 1) * HR_BYTES);
     if (sb + 1 < nsb) dma_rows(sb + 1);  // its buffer was last read before the previous super-block's barrier
+    if (sb > 0) store_res(sb - 1);
+    CE6_STAMP(sb == 0 ? 6 : 3);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       b8 Hr[2][3];
@@ -655,6 +689,7 @@ __global__ void __launch_bounds__(64 * NWF) ce6_fwd_kernel(const acattn_ce_probl
       _Pragma("unroll") for (int t = 0; t < FT; ++t) acc[t] = mfma_bf(Er[t][s][p], Hr[s][q], acc[t]);
       CE6_TERMS(CE6_F1)
 #undef CE6_F1
+      CE6_STAMP(0);
       if (ragged) {
 #pragma unroll
         for (int t = 0; t < FT; ++t)
@@ -666,9 +701,9 @@ __global__ void __launch_bounds__(64 * NWF) ce6_fwd_kernel(const acattn_ce_probl
 #pragma unroll
       for (int t = 0; t < FT; ++t) m = fmaxf(fmaxf(fmaxf(fmaxf(m, acc[t][0]), acc[t][1]), acc[t][2]), acc[t][3]);
       m = quad_max(m);
-      float sum = 0.f;
-      if (m > ACATTN_NEG_INF) {
-        const float m2 = m * kLog2e;
+      float sum;
+      {
+        const float m2 = m > ACATTN_NEG_INF ? m * kLog2e : 0.f;  // (no item: exp2(-inf) = 0, no branch)
         f4 sv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < FT; ++t) {
@@ -680,15 +715,17 @@ __global__ void __launch_bounds__(64 * NWF) ce6_fwd_kernel(const acattn_ce_probl
         sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
       }
       sum = quad_sum(sum);
-      const int row = 32 * sb + 16 * h + c;
-      if (g == 0 && row < B) part[(size_t)wid * B + row] = float2{m, sum};
+      if (g == 0) fold[((sb & 1) * NWF + wave) * 32 + 16 * h + c] = float2{m, sum};
+      CE6_STAMP(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    CE6_STAMP(2);
   }
+  store_res(nsb - 1);
   if (n_left > 0) {
     // leftover units (tile, super-block), n_left * nsb of them, dealt out evenly: wave w takes units [w U, (w + 1) U);
-    // operand images straight from global memory.  Partial number gridDim.x * NWF + tile.
+    // operand images straight from global memory.  Partial number gridDim.x + tile.
     const int n_units = n_left * nsb, U = (n_units + gridDim.x * NWF - 1) / (gridDim.x * NWF);
     const int first = wid * U, n_my = min(max(n_units - first, 0), U);
     int cur_tile = -1;
@@ -737,10 +774,15 @@ __global__ void __launch_bounds__(64 * NWF) ce6_fwd_kernel(const acattn_ce_probl
         }
         sum = quad_sum(sum);
         const int row = 32 * sb + 16 * h + c;
-        if (g == 0 && row < B) part[(size_t)(gridDim.x * NWF + tile) * B + row] = float2{m, sum};
+        if (g == 0 && row < B) part[(size_t)(gridDim.x + tile) * B + row] = float2{m, sum};
       }
     }
   }
+  CE6_STAMP(7);
+#ifdef ACATTN_CE_STAMPS
+  if (lane == 0 && wid < 4096)
+    for (int k = 0; k < 8; ++k) g_ce6_stamps[wid * 8 + k] = cyc_[k];
+#endif
 }
 
 // d_out[i] = sum over workgroups of slab[wg][i] (acattn_ce.hip's ce_bwd_reduce_kernel: 32 outputs per workgroup, 8 threads
@@ -830,10 +872,10 @@ int acattn_launch_ce6_onehot_reduce(const acattn_ce_problem& p, const float* coe
   return (int)hipGetLastError();
 }
 
-// Forward partials: (n_wg * 8 + n_left) x B (max, sum-exp) pairs in `part`.
+// Forward partials: (n_wg + n_left) x B (max, sum-exp) pairs in `part`.
 int acattn_launch_ce6_fwd_sweep(const acattn_ce_problem& p, float2* part, void* rows_ws, int n_wg, int n_left, hipStream_t stream) {
   b8* Hb = (b8*)rows_ws;
   hipLaunchKernelGGL(ce_split_rows_kernel, dim3((p.B + 31) / 32), dim3(256), 0, stream, p.out, p.B, Hb);
-  hipLaunchKernelGGL(ce6_fwd_kernel, dim3(n_wg), dim3(64 * NWF), 2 * HR_BYTES, stream, p, part, (const b8*)Hb, n_left);
+  hipLaunchKernelGGL(ce6_fwd_kernel, dim3(n_wg), dim3(64 * NWF), 2 * HR_BYTES + 2 * NWF * 32 * sizeof(float2), stream, p, part, (const b8*)Hb, n_left);
   return (int)hipGetLastError();
 }

@@ -43,3 +43,22 @@ dump("backward with table gradient")
 for _ in range(3):
     loss = ce.full_sort_cross_entropy(out, table.detach(), target, table_grad=False)
 dump("forward with direction")
+names = ["P1 (operand reads + MFMAs)", "soft-max arithmetic + LDS store", "wait + barrier", "DMA issue + fold of previous", "-", "-", "prologue (table operands, first DMA)", "leftover units"]
+lse_loss = ce.full_sort_cross_entropy(out.detach(), table.detach(), target)
+for _ in range(3):
+    lse_loss = ce.full_sort_cross_entropy(out.detach(), table.detach(), target)
+
+
+def dump_fwd(label):
+    torch.cuda.synchronize()
+    n_waves = 2048
+    buf = (C.c_ulonglong * (n_waves * 8))()
+    assert fn(buf, n_waves * 8) == 0
+    s = np.frombuffer(buf, dtype=np.uint64).reshape(n_waves, 8).astype(np.int64)
+    tot = s.sum(axis=1)
+    print(label, "- cycles per wave: mean total", int(tot.mean()), "max", int(tot.max()))
+    for k, n in enumerate(names):
+        print(f"    {n:38s} mean {s[:, k].mean():9.0f}  ({100 * s[:, k].mean() / tot.mean():4.1f} %)   per super-block {s[:, k].mean() / 16:7.0f}   max wave {s[:, k].max():8d}")
+
+
+dump_fwd("forward (eight waves of three tiles)")
