@@ -39,6 +39,12 @@ constexpr int NW = 4;            // waves per workgroup
 constexpr int ES = CH + 4;       // fp32 row stride of a parked [rows][CH] tile
 constexpr int HSLOTS = 24;       // operand slots of a super-block: 12 by row ((h, s, q)), 12 by column ((q, cb))
 constexpr int HB_BYTES = HSLOTS * 64 * 16;
+#ifndef CE6_EC_AGPR
+#define CE6_EC_AGPR 1
+#endif
+#ifndef CE6_PIPE
+#define CE6_PIPE 0  // vector instructions asked for behind every MFMA of a pipelined product; 0 = phases in program order
+#endif
 
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b4 __attribute__((ext_vector_type(4)));
@@ -77,8 +83,11 @@ __device__ __forceinline__ void split8(const float (&x)[8], b8& p0, b8& p1, b8& 
 // One workgroup per super-block of 32 batch rows: the rows' operand images.
 //   slot (2h + s) * 3 + q,  lane (c, g): plane q of out[32 sb + 16 h + c][32 s + 8 g + j]          (P1's B operand)
 //   slot 12 + 4 q + cb,     lane (c, g): plane q of out[32 sb + 8 g + j][16 cb + c]                  (P3's B operand)
-__global__ void __launch_bounds__(256) ce_split_rows_kernel(const float* __restrict__ out, const int B, b8* __restrict__ Hb) {
+// Also zeroes `n_zero` floats at `zero` (the leftover tiles' d_table rows when several workgroups add into them).
+__global__ void __launch_bounds__(256) ce_split_rows_kernel(const float* __restrict__ out, const int B, b8* __restrict__ Hb,
+                                                            float* __restrict__ zero, const int64_t n_zero) {
   const int sb = blockIdx.x;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * 256) zero[i] = 0.f;
   for (int e = threadIdx.x; e < 8 * 64; e += 256) {
     const int grp = e >> 6, lane = e & 63, c = lane & 15, g = lane >> 4;
     float x[8];
@@ -201,6 +210,13 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         x[j] = item < N ? v : 0.f;
       }
       split8(x, Ec[u][cb][0], Ec[u][cb][1], Ec[u][cb][2]);
+#if CE6_EC_AGPR
+      // The two table images are 288 registers, more than the 256 architectural ones: left to itself the allocator parks the
+      // excess in accumulator registers as SPILLS and copies four dwords back in front of every MFMA that uses them.  An
+      // MFMA reads its A / B operands from accumulator registers directly: this image is pinned there for the sweep.
+#pragma unroll
+      for (int p = 0; p < 3; ++p) asm volatile("" : "+a"(Ec[u][cb][p]));
+#endif
     }
   }
   f4 dE[TILES][4];
@@ -244,17 +260,13 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
       cf_cur[h] = cf_next[h];
     }
     if (sb + 1 < nsb) prefetch(sb + 1);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      CE6_STAMP(-1);
-      const bool row_ok = 32 * sb + 16 * h + c < B;
-      // ---- P1: logits^T of the wave's items for the half's 16 rows -------------------------------------------------
+    // The half's phases as pieces, so that they can be issued in a software-pipelined order below.
+    auto p1 = [&](const int h, f4 (&dl)[TILES]) {  // P1: logits^T of the wave's items for the half's 16 rows
       b8 Hr[2][3];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int q = 0; q < 3; ++q) Hr[s][q] = Hs[((2 * h + s) * 3 + q) * 64 + lane];
-      f4 dl[TILES];
 #pragma unroll
       for (int t = 0; t < TILES; ++t) dl[t] = f4{0.f, 0.f, 0.f, 0.f};
 #define CE6_P1(p, q)                                                                  \
@@ -262,8 +274,8 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
       _Pragma("unroll") for (int t = 0; t < TILES; ++t) dl[t] = mfma_bf(Er[t][s][p], Hr[s][q], dl[t]);
       CE6_TERMS(CE6_P1)
 #undef CE6_P1
-      CE6_STAMP(0);
-      // ---- soft-max arithmetic (acattn_ce.hip's, the layout is the same) -------------------------------------------
+    };
+    auto ragged_fix = [&](f4 (&dl)[TILES]) {
       if (ragged) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
@@ -271,8 +283,12 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
           for (int r = 0; r < 4; ++r)
             if (item0 + 16 * t + 4 * g + r >= N) dl[t][r] = ACATTN_NEG_INF;  // exp2(-inf) = 0 past the catalogue end
       }
-      float m_w = ACATTN_NEG_INF, s_w = 0.f;  // DIR: this wave's maximum and sum-exp for batch row c
+    };
+    // soft-max arithmetic (acattn_ce.hip's, the layout is the same), then the split of dl: its planes are P2's B operand
+    // as they stand, and go to the transpose image for P3
+    auto valu = [&](const int h, f4 (&dl)[TILES], b8 (&dlB)[C::UP][3], float& m_w, float& s_w) {
       if (DIR) {
+        m_w = ACATTN_NEG_INF;
 #pragma unroll
         for (int t = 0; t < TILES; ++t) m_w = fmaxf(fmaxf(fmaxf(fmaxf(m_w, dl[t][0]), dl[t][1]), dl[t][2]), dl[t][3]);
         m_w = quad_max(m_w);
@@ -299,9 +315,6 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
           dl[t] = x * cf;
         }
       }
-      CE6_STAMP(1);
-      // ---- split dl; its planes are P2's B operand as they stand, and go to the transpose image for P3 -------------
-      b8 dlB[C::UP][3];
 #pragma unroll
       for (int u = 0; u < C::UP; ++u) {
         float x[8];
@@ -322,9 +335,8 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
             *(b4*)(dst + 32) = __builtin_shufflevector(dlB[u][p], dlB[u][p], 4, 5, 6, 7);  // items 16(2u + 1) + 4g ..
           }
       }
-      CE6_STAMP(2);
-      // ---- P2: d out^T (this wave's items) = E^T . dl^T -------------------------------------------------------------
-      f4 dh[4];
+    };
+    auto p2 = [&](const b8 (&dlB)[C::UP][3], f4 (&dh)[4]) {  // P2: d out^T (this wave's items) = E^T . dl^T
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) dh[cb] = f4{0.f, 0.f, 0.f, 0.f};
 #define CE6_P2(p, q)                                                                  \
@@ -332,15 +344,64 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
       _Pragma("unroll") for (int cb = 0; cb < 4; ++cb) dh[cb] = mfma_bf(Ec[u][cb][p], dlB[u][q], dh[cb]);
       CE6_TERMS(CE6_P2)
 #undef CE6_P2
-      // park the half's [16][CH] tile for the fold
+    };
+    auto park_tile = [&](const int h, const f4 (&dh)[4], const float m_w, const float s_w) {  // the half's [16][CH] tile, for the fold
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) *(f4*)(Pw + (16 * h + c) * ES + 16 * cb + 4 * g) = dh[cb];
       if (DIR && g == 0) {  // (max, sum-exp) of this wave for the row, in the pad columns of its parked tile
         Pw[(16 * h + c) * ES + CH] = m_w;
         Pw[(16 * h + c) * ES + CH + 1] = s_w;
       }
+    };
+    // one MFMA, then `nv` vector instructions, `n` times: the order the scheduler is asked for inside the current region
+    auto interleave = [&](auto n_mfma, auto n_valu) {
+#pragma unroll
+      for (int i = 0; i < decltype(n_mfma)::value; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, decltype(n_valu)::value, 0);
+      }
+    };
+    float m_w[2] = {ACATTN_NEG_INF, ACATTN_NEG_INF}, s_w[2] = {0.f, 0.f};
+    f4 dh[4];
+#if CE6_PIPE
+    // Software pipeline: the second half's logits product is issued with the first half's soft-max / split arithmetic
+    // in between its MFMAs (a bf16 MFMA holds the issue port for half of its 16 cycles), and the first half's d_out
+    // product with the second half's arithmetic.  One wave per SIMD: nothing else would fill those slots.
+    CE6_STAMP(-1);
+    f4 dl0[TILES], dl1[TILES];
+    b8 dlB0[C::UP][3], dlB1[C::UP][3];
+    p1(0, dl0);
+    ragged_fix(dl0);
+    CE6_STAMP(0);
+    p1(1, dl1);
+    valu(0, dl0, dlB0, m_w[0], s_w[0]);
+    interleave(std::integral_constant<int, 12 * TILES>{}, std::integral_constant<int, CE6_PIPE>{});
+    ragged_fix(dl1);
+    CE6_STAMP(1);
+    p2(dlB0, dh);
+    valu(1, dl1, dlB1, m_w[1], s_w[1]);
+    interleave(std::integral_constant<int, 24 * C::UP>{}, std::integral_constant<int, CE6_PIPE>{});
+    CE6_STAMP(2);
+    park_tile(0, dh, m_w[0], s_w[0]);
+    p2(dlB1, dh);
+    park_tile(1, dh, m_w[1], s_w[1]);
+    CE6_STAMP(3);
+#else
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      CE6_STAMP(-1);
+      f4 dl[TILES];
+      b8 dlB[C::UP][3];
+      p1(h, dl);
+      CE6_STAMP(0);
+      ragged_fix(dl);
+      valu(h, dl, dlB, m_w[h], s_w[h]);
+      CE6_STAMP(2);
+      p2(dlB, dh);
+      park_tile(h, dh, m_w[h], s_w[h]);
       CE6_STAMP(3);
     }
+#endif
     if (WITH_TABLE_GRAD) {
       // ---- P3: d E (this wave's items) += dl^T . out over the super-block's 32 rows --------------------------------
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is the wave's own: its stores have landed, no barrier
@@ -402,7 +463,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
     __syncthreads();  // the parked tiles are free
     CE6_STAMP(5);
   }
-  if (WITH_TABLE_GRAD) {
+  auto store_dE = [&]() {  // the wave's d_table rows
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -413,7 +474,8 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
           for (int cb = 0; cb < 4; ++cb) d_table[(size_t)item * CH + 16 * cb + c] = dE[t][cb][r];
         }
       }
-  }
+  };
+  if (WITH_TABLE_GRAD && n_left <= 0) store_dE();
   if (n_left > 0) {
     // Leftover tiles behind the whole rounds (acattn_ce.hip's scheme): a UNIT is (leftover tile, super-block).  With a
     // table gradient workgroup l < n_left takes all of tile l, its waves every fourth super-block, so that the tile's
@@ -423,10 +485,15 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
     // Results: slab / partial number gridDim.x + tile.
     const int wid = blockIdx.x * NW + wave;
     int first, stride, n_my;
+    // (with a table gradient: `pieces` workgroups share a tile, a run of super-blocks each, when there are at least twice
+    // as many workgroups as leftover tiles; their d_table sums are then ADDED to rows that ce_split_rows_kernel zeroed)
+    const int pieces = WITH_TABLE_GRAD ? max(1, (int)gridDim.x / n_left) : 1;
+    const int tile_mine = blockIdx.x / pieces;
     if (WITH_TABLE_GRAD) {
-      first = blockIdx.x * nsb + wave;
+      const int per = (nsb + pieces - 1) / pieces, lo = (blockIdx.x % pieces) * per, hi = min(nsb, lo + per);
+      first = tile_mine * nsb + lo + wave;
       stride = NW;
-      n_my = (int)blockIdx.x < n_left ? (nsb - wave + NW - 1) / NW : 0;
+      n_my = tile_mine < n_left ? max(0, (hi - lo - wave + NW - 1) / NW) : 0;
     } else {
       const int n_units = n_left * nsb, U = (n_units + gridDim.x * NW - 1) / (gridDim.x * NW);
       first = wid * U;
@@ -438,13 +505,18 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
     f4 dE1[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) dE1[cb] = f4{0.f, 0.f, 0.f, 0.f};
+    // A unit's operands (24 images, the rows' lse / coef; on a tile change the tile's table rows) are REQUESTED one unit
+    // ahead -- the first unit's in front of the store of the main sweep's d_table rows -- and taken over when it starts:
+    // a wave has two units or so and each request is a full L2 / HBM round trip.
     b8 Hn[HSLOTS];
+    f4 er_n[2][2];
+    float ec_n[4][4];
     float lse_n[2] = {0.f, 0.f}, cf_n[2] = {0.f, 0.f};
-    auto fetch = [&](int u) {
-      const int sb = u % nsb;
+    auto request = [&](const int u, const bool with_tile) {
+      const int tile = u / nsb, sb = u - tile * nsb;
       const b8* src = Hb + (size_t)sb * HSLOTS * 64 + lane;
 #pragma unroll
-      for (int k = 0; k < HSLOTS; ++k) Hn[k] = src[k * 64];
+      for (int i = 0; i < HSLOTS; ++i) Hn[i] = src[i * 64];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = 32 * sb + 16 * h + c;
@@ -452,24 +524,36 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         lse_n[h] = (ok && !DIR) ? lse[row] : 0.f;
         cf_n[h] = (ok && !DIR) ? coef[P.coef_is_scalar ? 0 : row] * (P.coef_scale != 0.f ? P.coef_scale : 1.0f) : 0.f;
       }
+      if (with_tile) {  // (uniform per wave)
+        const int itx = gridDim.x * NW * C::ITEMS + 16 * tile;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const float* tsrc = P.table + (size_t)min(itx + c, N - 1) * CH + 32 * s + 8 * g;
+          er_n[s][0] = *(const f4*)tsrc;
+          er_n[s][1] = *(const f4*)(tsrc + 4);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ec_n[cb][j] = P.table[(size_t)min(itx + 4 * g + j, N - 1) * CH + 16 * cb + c];
+      }
     };
-    if (n_my > 0) fetch(first);
+    if (n_my > 0) request(first, true);
+    if (WITH_TABLE_GRAD) store_dE();
     int cur_tile = -1;
     for (int k = 0; k < n_my; ++k) {
       const int u = first + k * stride, tile = u / nsb, sb = u - tile * nsb;
       const int itx = gridDim.x * NW * C::ITEMS + 16 * tile;  // first item of the leftover tile
       const size_t vslab = (size_t)(gridDim.x + tile) * B;    // row offset of this tile's slab / partials
-      if (tile != cur_tile) {  // (uniform per wave)
+      if (tile != cur_tile) {  // (uniform per wave) the requested table rows -> split operands
         cur_tile = tile;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const float* src = P.table + (size_t)min(itx + c, N - 1) * CH + 32 * s + 8 * g;
-          const f4 v0 = *(const f4*)src, v1 = *(const f4*)(src + 4);
           float x[8];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            x[j] = itx + c < N ? v0[j] : 0.f;
-            x[4 + j] = itx + c < N ? v1[j] : 0.f;
+            x[j] = itx + c < N ? er_n[s][0][j] : 0.f;
+            x[4 + j] = itx + c < N ? er_n[s][1][j] : 0.f;
           }
           split8(x, Er1[s][0], Er1[s][1], Er1[s][2]);
         }
@@ -478,9 +562,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
           float x[8];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int item = itx + 4 * g + j;
-            const float v = P.table[(size_t)min(item, N - 1) * CH + 16 * cb + c];
-            x[j] = item < N ? v : 0.f;
+            x[j] = itx + 4 * g + j < N ? ec_n[cb][j] : 0.f;
             x[4 + j] = 0.f;
           }
           split8(x, Ec1[cb][0], Ec1[cb][1], Ec1[cb][2]);
@@ -495,15 +577,21 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         l2_u[h] = lse_n[h] * kLog2e;
         cf_u[h] = cf_n[h];
       }
-      if (k + 1 < n_my) fetch(first + (k + 1) * stride);
+      if (k + 1 < n_my) {
+        const int un = first + (k + 1) * stride;
+        request(un, un / nsb != tile);
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = 32 * sb + 16 * h + c;
-        f4 a = {0.f, 0.f, 0.f, 0.f};
-#define CE6_L1(p, q) \
-  _Pragma("unroll") for (int s = 0; s < 2; ++s) a = mfma_bf(Er1[s][p], Hq[(2 * h + s) * 3 + q], a);
+        f4 a, a1 = {0.f, 0.f, 0.f, 0.f};  // (two chains: a dependent MFMA waits out the previous one's passes)
+        a = a1;
+#define CE6_L1(p, q)                                        \
+  a = mfma_bf(Er1[0][p], Hq[(2 * h + 0) * 3 + q], a);      \
+  a1 = mfma_bf(Er1[1][p], Hq[(2 * h + 1) * 3 + q], a1);
         CE6_TERMS(CE6_L1)
 #undef CE6_L1
+        a += a1;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (itx + 4 * g + r >= N) a[r] = ACATTN_NEG_INF;
@@ -564,8 +652,8 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
 #undef CE6_L3
       }
     }
-    if (WITH_TABLE_GRAD && (int)blockIdx.x < n_left) {  // the four waves' shares of the tile's d_table rows meet in the parked-tile areas
-      const int itx = gridDim.x * NW * C::ITEMS + 16 * blockIdx.x;
+    if (WITH_TABLE_GRAD && tile_mine < n_left) {  // the four waves' shares of the tile's d_table rows meet in the parked-tile areas
+      const int itx = gridDim.x * NW * C::ITEMS + 16 * tile_mine;
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -576,7 +664,10 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += park[w * C::PARK_FLOATS + i * ES + hcol];
-        if (itx + i < N) d_table[(size_t)(itx + i) * CH + hcol] = v;
+        if (itx + i < N) {
+          if (pieces > 1) atomicAdd(d_table + (size_t)(itx + i) * CH + hcol, v);
+          else d_table[(size_t)(itx + i) * CH + hcol] = v;
+        }
       }
     }
   }
@@ -840,7 +931,14 @@ int acattn_launch_ce6_sweep(const acattn_ce_problem& p, const float* lse, const 
                             float2* part, void* rows_ws, int n_wg, int n_left, bool dir, hipStream_t stream) {
   using C = Ce6<6>;
   b8* Hb = (b8*)rows_ws;
-  hipLaunchKernelGGL(ce_split_rows_kernel, dim3((p.B + 31) / 32), dim3(256), 0, stream, p.out, p.B, Hb);
+  float* zero = nullptr;
+  int64_t n_zero = 0;
+  if (d_table && !dir && n_left > 0 && n_wg / n_left > 1) {  // (the kernel's `pieces` > 1)
+    const int64_t first_item = (int64_t)n_wg * NW * C::ITEMS;
+    zero = d_table + first_item * CH;
+    n_zero = (p.N - first_item) * CH;
+  }
+  hipLaunchKernelGGL(ce_split_rows_kernel, dim3((p.B + 31) / 32), dim3(256), 0, stream, p.out, p.B, Hb, zero, n_zero);
   const size_t lds = C::LDS_BYTES;
   if (dir) {
     auto k = ce6_bwd_kernel<6, false, true>;
@@ -875,7 +973,7 @@ int acattn_launch_ce6_onehot_reduce(const acattn_ce_problem& p, const float* coe
 // Forward partials: (n_wg + n_left) x B (max, sum-exp) pairs in `part`.
 int acattn_launch_ce6_fwd_sweep(const acattn_ce_problem& p, float2* part, void* rows_ws, int n_wg, int n_left, hipStream_t stream) {
   b8* Hb = (b8*)rows_ws;
-  hipLaunchKernelGGL(ce_split_rows_kernel, dim3((p.B + 31) / 32), dim3(256), 0, stream, p.out, p.B, Hb);
+  hipLaunchKernelGGL(ce_split_rows_kernel, dim3((p.B + 31) / 32), dim3(256), 0, stream, p.out, p.B, Hb, (float*)nullptr, (int64_t)0);
   hipLaunchKernelGGL(ce6_fwd_kernel, dim3(n_wg), dim3(64 * NWF), 2 * HR_BYTES + 2 * NWF * 32 * sizeof(float2), stream, p, part, (const b8*)Hb, n_left);
   return (int)hipGetLastError();
 }

@@ -36,6 +36,13 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert sorted(_lib.SYMBOLS) == names
 
 
+def test_ce_products_mode_query_needs_no_gpu(lib):
+    # (acattn_full_sort_ce_products: 0 exact fp32 MFMA, 1 default, 2 split sweeps everywhere; other values only query)
+    old = lib.acattn_full_sort_ce_products(-1)
+    assert old in (0, 1, 2)
+    assert lib.acattn_full_sort_ce_products(2) == old and lib.acattn_full_sort_ce_products(old) == 2
+
+
 def test_abi_version(lib):
     assert lib.acattn_abi_version() == _lib.ABI_VERSION
 

@@ -169,3 +169,84 @@ def test_dense_cross_entropy_equals_torch(rows, N):
     bad = target.clone()
     bad[1] = N
     assert torch.isnan(ce.dense_cross_entropy_rows(logits, bad)[1]) and torch.isfinite(ce.dense_cross_entropy_rows(logits, bad)[0])
+
+
+# --- [round 4] split products (acattn_ce_bf16.hip): every fp32 operand as three bf16 numbers, six bf16 MFMAs per product ---
+def _ce_errors(B, N, scale, mode, table_grad):
+    from ac_tsr_amd._lib import load
+    lib = load()
+    old = lib.acattn_full_sort_ce_products(mode)
+    try:
+        g = torch.Generator().manual_seed(B + 3 * N)
+        out = scale * torch.randn(B, 64, generator=g)
+        table = scale * torch.randn(N, 64, generator=g)
+        target = torch.randint(0, N, (B,), generator=g)
+        target[: B // 4] = N - 1 - torch.arange(B // 4) % min(N, 1500)
+        od = out.double().to(DEV).requires_grad_(True)
+        td = table.double().to(DEV).requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(od @ td.t(), target.to(DEV))
+        g_out, g_tab = torch.autograd.grad(ref, [od, td])
+        o = out.to(DEV).requires_grad_(True)
+        t = table.to(DEV).requires_grad_(True)
+        if table_grad:
+            loss = ce.full_sort_cross_entropy(o, t, target.to(DEV))
+            d_o, d_t = torch.autograd.grad(loss, [o, t])
+            e_t = ((d_t.double() - g_tab).abs().max() / g_tab.abs().max()).item()
+        else:
+            loss = ce.full_sort_cross_entropy(o, t.detach(), target.to(DEV), table_grad=False)
+            (d_o,) = torch.autograd.grad(loss, [o])
+            e_t = 0.0
+        e_l = abs(loss.item() - ref.item()) / abs(ref.item())
+        e_o = ((d_o.double() - g_out).abs().max() / g_out.abs().max()).item()
+        return e_l, e_o, e_t
+    finally:
+        lib.acattn_full_sort_ce_products(old)
+
+
+@pytest.mark.parametrize("B,N", [(512, 100000), (70, 99990), (37, 1000), (33, 385), (64, 5000), (45, 90000)])
+@pytest.mark.parametrize("scale", [0.02, 1.0])
+@pytest.mark.parametrize("table_grad", [True, False])
+def test_split_products_are_as_accurate_as_fp32_products(B, N, scale, table_grad):
+    """Errors against fp64 (loss relative; gradients relative to their largest element) of the split-product sweeps
+    (mode 2: for every catalogue size) next to the exact-fp32-MFMA kernels' (mode 0) on the same inputs: the split form
+    must stay within 2x of the fp32 form's error + 2e-7 (one fp32 rounding of the scale), far inside the suite's 1e-5 /
+    1e-4 tolerances.  Measured: equal or smaller in most cells (profiles/r04_ce_split_accuracy.txt)."""
+    a = _ce_errors(B, N, scale, 0, table_grad)
+    b = _ce_errors(B, N, scale, 2, table_grad)
+    for name, ea, eb in zip(("loss", "d_out", "d_table"), a, b):
+        assert eb <= 2.0 * ea + 2e-7, (name, ea, eb)
+        assert eb <= 2e-5, (name, eb)
+
+
+def test_products_mode_is_a_process_wide_switch_with_a_query():
+    from ac_tsr_amd._lib import load
+    lib = load()
+    old = lib.acattn_full_sort_ce_products(-1)  # query
+    assert old in (0, 1, 2)
+    assert lib.acattn_full_sort_ce_products(0) == old
+    assert lib.acattn_full_sort_ce_products(7) == 0  # out of range: query only
+    assert lib.acattn_full_sort_ce_products(old) == 0
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_invalid_target_gives_nan_loss_and_no_out_of_bounds_access(mode):
+    """A target outside [0, N): NaN row loss (ce_fwd_reduce_kernel), and neither form reads or writes a table row for it
+    (the split form applies the one-hot in ce6_onehot_reduce_kernel, which skips the row)."""
+    from ac_tsr_amd._lib import load
+    lib = load()
+    old = lib.acattn_full_sort_ce_products(mode)
+    try:
+        g = torch.Generator().manual_seed(5)
+        out = torch.randn(40, 64, generator=g).to(DEV).requires_grad_(True)
+        table = torch.randn(700, 64, generator=g).to(DEV).requires_grad_(True)
+        target = torch.randint(0, 700, (40,), generator=g)
+        target[3] = -100
+        target[9] = 700
+        rows = ce.full_sort_cross_entropy_rows(out, table, target.to(DEV))
+        assert torch.isnan(rows[3]) and torch.isnan(rows[9]) and torch.isfinite(rows[[0, 1, 2, 4]]).all()
+        ok = torch.ones(40, dtype=torch.bool)
+        ok[3] = ok[9] = False
+        d_o, d_t = torch.autograd.grad(rows[ok.to(DEV)].sum(), [out, table])
+        assert torch.isfinite(d_o).all() and torch.isfinite(d_t).all()
+    finally:
+        lib.acattn_full_sort_ce_products(old)
