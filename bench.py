@@ -31,6 +31,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def _ce_products_mode(a):
+    """How the full-catalogue cross-entropy evaluates its products in this run (include/acattn.h ABI 28)."""
+    from ac_tsr_amd._lib import load
+    mode = load().acattn_full_sort_ce_products(-1)
+    if mode == 0:
+        return "fp32 MFMA (v_mfma_f32_16x16x4_f32)"
+    split = "fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulation (fp32 accuracy: tests/test_hip_ce.py)"
+    applies = mode == 2 or (getattr(a, "hidden", 0) == 64 and 81920 < getattr(a, "items", 0) <= 102400)
+    return split if applies else "fp32 MFMA (the split sweeps cover hidden 64 with 81,921..102,400 items)"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -530,6 +541,7 @@ def main():
                 "parallelism": f"dp{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if rehearsal else ""), "launch": "eager" if a.no_graph else "hipGraph replay per step",
                 "backward": "one combined walk (opt-in)" if a.combined_backward else "two walks (reference protocol, trainer.py:672-686)",
                 "final_losses": [round(att, 4), round(cal, 4)],
+                "ce_products": _ce_products_mode(a),
                 "reference_schedule": None if full_ms is None else {
                     "ms_per_step": round(full_ms, 3), "value": round(a.batch / full_ms * 1e3, 1),
                     "note": "same step computing also the provably dead work the reference computes (DESIGN.md 5)"}},
