@@ -103,7 +103,9 @@ int acattn_launch_bwd(const acattn_problem& p, const acattn_bwd_io& io, hipStrea
       return -1;
     }
   }
-  const bool short_rows = p.L <= 64;
+  // (ACATTN_BWD_SHORT_STREAM=1, measurement: the streaming pair for L <= 64 as well)
+  static const bool short_stream = getenv("ACATTN_BWD_SHORT_STREAM") && atoi(getenv("ACATTN_BWD_SHORT_STREAM")) != 0;
+  const bool short_rows = p.L <= 64 && !short_stream;
   if (which == ACATTN_BWD_AUTO && short_rows) {
     const int rc_fast = acattn_launch_bwd_fast(p, io, stream);
     if (rc_fast != -100) return rc_fast;
