@@ -316,14 +316,32 @@ __global__ void __launch_bounds__(256) attacked_loss_finish_rows_kernel(const fl
     __syncthreads();
     return r;
   };
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < B; i += 256) acc += row_loss[i];
-  const float ce = block_sum(acc) / (float)B;
+  // one workgroup sums B + n_masks * count values (13,312 per mask at L = 200): four 16-byte loads in flight per thread --
+  // a dependent dword load per 256 values was a chain of 52 L2 round trips per mask (37 us at L = 200, 11 at L = 50)
+  auto thread_sum = [&](const float* __restrict__ p, const int n) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const bool vec = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    const int n4 = vec ? n >> 2 : 0;
+    const f4* p4 = (const f4*)p;
+    int i = threadIdx.x;
+    for (; i + 768 < n4; i += 1024) {
+      const f4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+      a0 += (v0[0] + v0[1]) + (v0[2] + v0[3]);
+      a1 += (v1[0] + v1[1]) + (v1[2] + v1[3]);
+      a2 += (v2[0] + v2[1]) + (v2[2] + v2[3]);
+      a3 += (v3[0] + v3[1]) + (v3[2] + v3[3]);
+    }
+    for (; i < n4; i += 256) {
+      const f4 v = p4[i];
+      a0 += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (int j = 4 * n4 + threadIdx.x; j < n; j += 256) a1 += p[j];
+    return (a0 + a1) + (a2 + a3);
+  };
+  const float ce = block_sum(thread_sum(row_loss, B)) / (float)B;
   float pen = 0.f;
   for (int l = 0; l < n_masks; ++l) {
-    float a = 0.f;
-    for (int i = threadIdx.x; i < count; i += 256) a += R.pen[l][i];
-    const float nv = sqrtf(block_sum(a));
+    const float nv = sqrtf(block_sum(thread_sum(R.pen[l], count)));
     if (threadIdx.x == 0) out[2 + l] = nv;
     pen += nv;
   }
