@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ACATTN_LIB") or os.path.join(CSRC, "libacattn.so")  # ACATTN_LIB: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "acattn.h")
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 MAX_MASKS = 8  # ACATTN_MAX_MASKS
 NSTAT = 8
 MASK_STRUCTURED, MASK_DENSE_LL, MASK_DENSE_L = 0, 1, 2
@@ -128,6 +128,7 @@ class EmbedProblem(C.Structure):
 EMBED_BWD_CHUNKS = 8
 PENALTY_WS_FLOATS = 1024
 WGRAD_MAX_GROUP = 8
+WGRAD_MAX_REDUCE = 32
 
 # name -> (restype, argtypes); must list every symbol include/acattn.h declares (tests check this)
 SYMBOLS = {
@@ -184,6 +185,10 @@ SYMBOLS = {
     "acattn_linear_wgrad_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int32, C.c_int64, _f, C.c_void_p]),
     "acattn_linear_wgrad": (C.c_int, [_f, _f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _f, C.c_void_p]),
+    "acattn_linear_wgrad_grouped_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acattn_linear_wgrad_reduce_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_int32, C.c_void_p]),
     "acattn_select_forward_kernel": (C.c_int, [C.c_int]),
     "acattn_select_backward_kernel": (C.c_int, [C.c_int]),
     "acattn_calibrated_attention_bwd_workspace_bytes": (C.c_int64, [C.POINTER(Problem)]),

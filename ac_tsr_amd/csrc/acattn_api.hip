@@ -512,6 +512,50 @@ int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, c
   return rc;
 }
 
+int acattn_linear_wgrad_grouped_partial(const float* const* x, const float* const* dy, const int32_t* K, const int32_t* N,
+                                        const int32_t* want_bias, int32_t n_items, int64_t M, void* workspace, int32_t* n_partials,
+                                        int64_t* w_offset, int64_t* b_offset, void* stream) {
+  if (!x || !dy || !K || !N || !want_bias || !workspace || !n_partials || !w_offset || !b_offset)
+    return fail("x, dy, K, N, want_bias, workspace, n_partials, w_offset and b_offset must be non-NULL");
+  if (n_items < 1 || n_items > ACATTN_WGRAD_MAX_GROUP) return fail("n_items must lie in [1, ACATTN_WGRAD_MAX_GROUP]");
+  if (M < 1) return fail("M must be positive");
+  float* dw[ACATTN_WGRAD_MAX_GROUP];
+  float* db[ACATTN_WGRAD_MAX_GROUP];
+  for (int i = 0; i < n_items; ++i) {
+    if (!x[i] || !dy[i]) return fail("every item needs x and dy");
+    if (K[i] < 1 || N[i] < 1) return fail("K and N must be positive");
+    if (M * (int64_t)std::max(K[i], N[i]) >= (1LL << 40)) return fail("matrix too large");
+    dw[i] = nullptr;                                   // (stage 1 writes partials only; db != NULL = "bias partials wanted")
+    db[i] = want_bias[i] ? (float*)workspace : nullptr;
+  }
+  int P = 0;
+  long long wo[ACATTN_WGRAD_MAX_GROUP], bo[ACATTN_WGRAD_MAX_GROUP];
+  const int rc = acattn_launch_linear_wgrad(x, dy, (const int*)K, (const int*)N, dw, db, n_items, M, workspace,
+                                            (hipStream_t)stream, &P, wo, bo);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  *n_partials = P;
+  for (int i = 0; i < n_items; ++i) {
+    w_offset[i] = wo[i];
+    b_offset[i] = bo[i];
+  }
+  return rc;
+}
+
+int acattn_linear_wgrad_reduce_many(const float* const* part_w, const float* const* part_b, const int32_t* K, const int32_t* N,
+                                    const int32_t* n_partials, float* const* dw, float* const* db, int32_t n_items, void* stream) {
+  if (!part_w || !part_b || !K || !N || !n_partials || !dw || !db) return fail("every array must be non-NULL");
+  if (n_items < 1 || n_items > ACATTN_WGRAD_MAX_REDUCE) return fail("n_items must lie in [1, ACATTN_WGRAD_MAX_REDUCE]");
+  for (int i = 0; i < n_items; ++i) {
+    if (!part_w[i] || !dw[i]) return fail("every item needs its partials and dw");
+    if (db[i] && !part_b[i]) return fail("db given without bias partials");
+    if (K[i] < 1 || N[i] < 1 || n_partials[i] < 1) return fail("K, N and n_partials must be positive");
+  }
+  const int rc = acattn_launch_linear_wgrad_reduce_many(part_w, part_b, (const int*)K, (const int*)N, (const int*)n_partials, dw, db,
+                                                        n_items, (hipStream_t)stream);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int acattn_linear_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, void* workspace, float* dw,
                         float* db, void* stream) {
   return acattn_linear_wgrad_grouped(&x, &dy, &K, &N, &dw, &db, 1, M, workspace, stream);

@@ -229,6 +229,73 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradGroup G, c
   }
 }
 
+// Stage 2 for up to ACATTN_WGRAD_MAX_REDUCE items of DIFFERENT launches of stage 1 (each with its own partial count and
+// workspace): a trainer defers the reductions of a whole backward walk to one launch (acattn_linear_wgrad_reduce_many).
+struct WgradMany {
+  const float* part_w[ACATTN_WGRAD_MAX_REDUCE];
+  const float* part_b[ACATTN_WGRAD_MAX_REDUCE];
+  float* dw[ACATTN_WGRAD_MAX_REDUCE];
+  float* db[ACATTN_WGRAD_MAX_REDUCE];
+  int K[ACATTN_WGRAD_MAX_REDUCE];
+  int N[ACATTN_WGRAD_MAX_REDUCE];
+  int P[ACATTN_WGRAD_MAX_REDUCE];
+};
+
+__global__ void __launch_bounds__(256) wgrad_reduce_many_kernel(const WgradMany G) {
+  const int it = blockIdx.z;
+  const int K = G.K[it], N = G.N[it];
+  const int KB = (K + 63) >> 6, NB = (N + 63) >> 6;
+  if ((int)blockIdx.y >= KB * NB) return;
+  float* __restrict__ dw = G.dw[it];
+  float* __restrict__ db = G.db[it];
+  const float* part_w = G.part_w[it];
+  const float* part_b = G.part_b[it];
+  const int P = G.P[it];
+  const int blk = blockIdx.y, nb = blk / KB, kb = blk - nb * KB;
+  // 32 slots per workgroup, 8 threads per slot; a thread sums every 8th partial with 8 loads in flight at a time
+  // (the kernel is a latency chain otherwise: 4 MB spread over few workgroups), folded through LDS
+  const int sl = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int s = blockIdx.x * 32 + sl;  // slot 0..4095
+  const float* pw = part_w + (size_t)blk * P * (kRegs * 64) + s;
+  constexpr size_t PS = kRegs * 64;
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  int p = q;
+  for (; p + 56 < P; p += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += pw[(size_t)(p + 8 * u) * PS];
+  }
+  for (; p < P; p += 8) a[0] += pw[(size_t)p * PS];
+  __shared__ float red[8][32];
+  red[q][sl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (q == 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += red[u][sl];
+    const int reg = s >> 6, lane = s & 63;
+    const int tile = reg >> 2, r = reg & 3, aa = tile >> 2, bb = tile & 3, g = lane >> 4, c = lane & 15;
+    const int n = nb * 64 + 4 * (4 * g + r) + aa, k = kb * 64 + 4 * c + bb;
+    if (n < N && k < K) dw[(size_t)n * K + k] = v;
+  }
+  if (db && kb == 0 && blockIdx.x < 2) {  // 2 workgroups x 32 columns
+    __syncthreads();
+    const int col = blockIdx.x * 32 + sl, nn = nb * 64 + col;
+    const float* pb = part_b + (size_t)nb * P * 64 + col;
+    float sb = 0.f;
+    for (int t = q; t < P; t += 8) sb += pb[(size_t)t * 64];
+    red[q][sl] = sb;
+    __syncthreads();
+    if (q == 0 && nn < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += red[u][sl];
+      db[nn] = v;
+    }
+  }
+}
+
 int pick_partials(int64_t M, int blocks) {
   // Measured on MI355X at M = 25,600 (tools/gpu_wgrad.sh): stage 1 takes ~10 us whether 128 or 256 workgroups
   // share a 64 x 64 block, stage 2 grows with the number of partials it folds -> few partials, but never fewer
@@ -259,7 +326,8 @@ int64_t acattn_linear_wgrad_ws_bytes(int64_t M, int K, int N) {
 
 // n_items problems sharing M (the workspace holds sum_i acattn_linear_wgrad_ws_bytes(M, K[i], N[i]) bytes)
 int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, const int* K, const int* N,
-                               float* const* dw, float* const* db, int n_items, int64_t M, void* ws, hipStream_t stream) {
+                               float* const* dw, float* const* db, int n_items, int64_t M, void* ws, hipStream_t stream,
+                               int* P_out, long long* w_off_out, long long* b_off_out) {
   WgradGroup G{};
   const int P = group_partials(M, K, N, n_items);
   int blocks = 1;
@@ -288,6 +356,32 @@ int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, co
     hipLaunchKernelGGL((wgrad_partial_kernel<1>), grid, dim3(256), 0, stream, G, M, (float*)ws);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
+  if (P_out) {  // stage 1 alone: the caller reduces later (acattn_launch_linear_wgrad_reduce_many)
+    *P_out = P;
+    for (int i = 0; i < n_items; ++i) {
+      w_off_out[i] = G.w_off[i];
+      b_off_out[i] = G.b_off[i];
+    }
+    return 0;
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kRegs * 2, blocks, n_items), dim3(256), 0, stream, G, (const float*)ws, P);
+  return (int)hipGetLastError();
+}
+
+int acattn_launch_linear_wgrad_reduce_many(const float* const* part_w, const float* const* part_b, const int* K, const int* N,
+                                           const int* P, float* const* dw, float* const* db, int n_items, hipStream_t stream) {
+  WgradMany G{};
+  int blocks = 1;
+  for (int i = 0; i < n_items; ++i) {
+    G.part_w[i] = part_w[i];
+    G.part_b[i] = part_b[i];
+    G.dw[i] = dw[i];
+    G.db[i] = db[i];
+    G.K[i] = K[i];
+    G.N[i] = N[i];
+    G.P[i] = P[i];
+    blocks = std::max(blocks, ((K[i] + 63) / 64) * ((N[i] + 63) / 64));
+  }
+  hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(kRegs * 2, blocks, n_items), dim3(256), 0, stream, G);
   return (int)hipGetLastError();
 }

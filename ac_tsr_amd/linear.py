@@ -55,7 +55,7 @@ class _SkinnyLinear(torch.autograd.Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and want_params
         if ctx.needs_input_grad[1] and want_params:
             from .ops import linear_wgrad
-            gw, gb = linear_wgrad(x.reshape(-1, x.shape[-1]), g2, want_b)
+            gw, gb = linear_wgrad(x.reshape(-1, x.shape[-1]), g2, want_b, ctx.state)
         elif want_b:
             gb = _sum_rows(g2, 0)
         return gx, gw, gb, None, None
@@ -134,7 +134,7 @@ class _Projections(torch.autograd.Function):
             params(11, mq2, dgate, others)
         if jobs:
             from .ops import linear_wgrad_grouped
-            for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs])):
+            for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs], ctx.state)):
                 grads[slot - 1], grads[slot] = gw, gb
         return (dx, *grads, None, None)
 
@@ -252,7 +252,7 @@ class _FusedProjections(torch.autograd.Function):
         if ctx.has_gate:
             want(11, mq, dgate, others)
         if jobs:
-            for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs])):
+            for (slot, _, _, _), (gw, gb) in zip(jobs, linear_wgrad_grouped([(i, g, wb) for _, i, g, wb in jobs], ctx.state)):
                 grads[slot - 1], grads[slot] = gw, gb
         return (dx, *grads, None, None, None)
 

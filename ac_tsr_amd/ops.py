@@ -497,9 +497,11 @@ def sum_rows(x: torch.Tensor, dim: int = 0) -> torch.Tensor:
     return _launch_sum_rows(x, batch, R, Cn, out_shape)
 
 
-def linear_wgrad(x2: torch.Tensor, g2: torch.Tensor, want_bias: bool):
+def linear_wgrad(x2: torch.Tensor, g2: torch.Tensor, want_bias: bool, state=None):
     """(dW [N,K], db [N] or None) of y = x W^T + b from x2 [M,K] and dy g2 [M,N] through acattn_linear_wgrad
     (one pass over both matrices, fp32 MFMA).  No autograd: used inside backward functions."""
+    if state is not None and state.deferring():
+        return linear_wgrad_grouped([(x2, g2, want_bias)], state)[0]
     assert x2.is_cuda and x2.dtype == torch.float32 and g2.dtype == torch.float32 and x2.shape[0] == g2.shape[0]
     x2, g2 = x2.contiguous(), g2.contiguous()
     M, K = x2.shape
@@ -538,10 +540,13 @@ def mask_penalty(attack_mask: torch.Tensor) -> torch.Tensor:
     return _MaskPenalty.apply(attack_mask)
 
 
-def linear_wgrad_grouped(items):
+def linear_wgrad_grouped(items, state=None):
     """[(dW, db or None), ...] for items = [(x2 [M,K_i], g2 [M,N_i], want_bias), ...]: items that share M go through
-    ONE acattn_linear_wgrad_grouped launch pair (at most WGRAD_MAX_GROUP per launch)."""
+    ONE acattn_linear_wgrad_grouped launch pair (at most WGRAD_MAX_GROUP per launch).  With a `state` that is
+    `deferring()` (a trainer's backward walk) only stage 1 is launched: the returned tensors are written by the
+    trainer's StepState.flush_deferred() at the end of the walk (state.py)."""
     lib = _lib.load()
+    defer = state is not None and state.deferring()
     out = [None] * len(items)
     buckets = {}
     for pos, (x, g, wb) in enumerate(items):
@@ -558,6 +563,23 @@ def linear_wgrad_grouped(items):
             dbs = [torch.empty(g.shape[1], device=dev, dtype=torch.float32) if wb else None for _, _, g, wb in chunk]
             arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
             ints = lambda vals: (C.c_int32 * n)(*vals)
+            if defer:
+                n_part = C.c_int32(0)
+                w_off, b_off = (C.c_int64 * n)(), (C.c_int64 * n)()
+                _lib.check(lib.acattn_linear_wgrad_grouped_partial(
+                    arr([x.data_ptr() for _, x, _, _ in chunk]), arr([g.data_ptr() for _, _, g, _ in chunk]),
+                    ints([x.shape[1] for _, x, _, _ in chunk]), ints([g.shape[1] for _, _, g, _ in chunk]),
+                    ints([1 if wb else 0 for _, _, _, wb in chunk]), n, M, _ptr(ws), C.byref(n_part), w_off, b_off, _stream()),
+                    "linear_wgrad_grouped_partial")
+                base = ws.data_ptr()
+                for k, ((pos, x, g, wb), gw, gb) in enumerate(zip(chunk, dws, dbs)):
+                    # the queue keeps the memory alive (storages), not the tensors: autograd adopts a gradient tensor as
+                    # a leaf's .grad without copying only while nobody else holds it
+                    state.defer({"part_w": base + 4 * w_off[k], "part_b": base + 4 * b_off[k], "K": x.shape[1], "N": g.shape[1],
+                                 "P": n_part.value, "dw": gw.data_ptr(), "db": None if gb is None else gb.data_ptr(),
+                                 "keep": (ws.untyped_storage(), gw.untyped_storage(), None if gb is None else gb.untyped_storage())})
+                    out[pos] = (gw, gb)
+                continue
             _lib.check(lib.acattn_linear_wgrad_grouped(
                 arr([x.data_ptr() for _, x, _, _ in chunk]), arr([g.data_ptr() for _, _, g, _ in chunk]),
                 ints([x.shape[1] for _, x, _, _ in chunk]), ints([g.shape[1] for _, _, g, _ in chunk]),

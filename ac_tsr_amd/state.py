@@ -20,11 +20,12 @@ import torch
 import os as _os
 _CONFLICT = object()  # StepState.table_grad: two nodes published in one pass
 _NO_HANDOVER = _os.environ.get("ACATTN_NO_HANDOVER") == "1"  # measurement / bisection hook
+_NO_DEFER = _os.environ.get("ACATTN_NO_DEFER") == "1"  # measurement / bisection hook: every wgrad reduction where it is due
 
 
 class StepState:
     __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "grad_home", "_frozen",
-                 "_home_claimed", "affine_ws", "combined")
+                 "_home_claimed", "affine_ws", "combined", "defer_reductions", "_deferred")
 
     def __init__(self, frozen: bool = False):
         object.__setattr__(self, "_frozen", False)
@@ -63,6 +64,15 @@ class StepState:
         self.affine_ws = {}
         # combined.CombinedWalk while a single-pass combined backward runs (trainer, opt-in), else None
         self.combined = None
+        # [r4] Deferred weight-gradient reductions (ops.linear_wgrad_grouped): inside a trainer's backward walk the nodes
+        # launch only stage 1 of acattn_linear_wgrad (partial sums) and hand autograd an unwritten tensor; the trainer
+        # calls flush_deferred() when the walk is over and ONE stage-2 launch writes every such tensor (six launches of
+        # ~6 us per step become two).  Sound only because (a) nothing reads a parameter gradient before the walk ends,
+        # (b) autograd ADOPTS the tensor it is handed for a leaf whose .grad is None (AccumulateGrad's use_count test:
+        # the queue keeps the storage alive, not the tensor) -- flush_deferred verifies (b) for every job and raises
+        # otherwise.  Set by the trainer (AttackSASRecTrainer); off anywhere else.
+        self.defer_reductions = False
+        self._deferred = []
         object.__setattr__(self, "_frozen", frozen)
 
     def __setattr__(self, name, value):
@@ -83,6 +93,8 @@ class StepState:
         self.table_grad = self.grad_home = self._home_claimed = None
         self.affine_ws = {}
         self.combined = None
+        self.defer_reductions = False
+        self._deferred = []
         object.__setattr__(self, "_frozen", st["frozen"])
 
     def __copy__(self):
@@ -97,6 +109,7 @@ class StepState:
         new.grad_home = None
         new.affine_ws = {}
         new.combined = None
+        new.defer_reductions = False
         memo[id(self)] = new
         return new
 
@@ -170,6 +183,44 @@ class StepState:
         # a fresh tensor object on the same memory: autograd keeps a gradient without copying it only if nobody else
         # holds the tensor object (AccumulateGrad's use_count test), and the synchronizer holds `home`
         return None if home is None else home.view_as(home)
+
+    # ---- deferred weight-gradient reductions (see __init__) ------------------------------------------------------------
+    def deferring(self) -> bool:
+        """May a node of the walk that is running leave its stage-2 reduction to flush_deferred()?"""
+        return (not self._frozen and self.defer_reductions and self.combined is None
+                and self.pass_mode in ("calibrated", "attack") and not _NO_DEFER)
+
+    def defer(self, job) -> None:
+        self._deferred.append(job)
+
+    def flush_deferred(self, params) -> None:
+        """End of a backward walk over the leaves `params`: one stage-2 launch per ACATTN_WGRAD_MAX_REDUCE queued items.
+        Every queued destination must by now BE the .grad of one of `params` (same memory): anything else means autograd
+        copied the unwritten tensor instead of adopting it, and the step would train on garbage -- raise."""
+        jobs, self._deferred = self._deferred, []
+        if not jobs:
+            return
+        import ctypes as C
+        from . import _lib
+        owned = {p.grad.data_ptr() for p in params if p.grad is not None}
+        for j in jobs:
+            for ptr in (j["dw"], j["db"]):
+                if ptr is not None and ptr not in owned:
+                    raise RuntimeError("a deferred weight gradient was not adopted by autograd as the parameter's .grad "
+                                       "(ACATTN_NO_DEFER=1 switches the deferral off)")
+        lib = _lib.load()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for s0 in range(0, len(jobs), _lib.WGRAD_MAX_REDUCE):
+            chunk = jobs[s0:s0 + _lib.WGRAD_MAX_REDUCE]
+            n = len(chunk)
+            arr = lambda key: (C.c_void_p * n)(*(j[key] for j in chunk))
+            ints = lambda key: (C.c_int32 * n)(*(j[key] for j in chunk))
+            _lib.check(lib.acattn_linear_wgrad_reduce_many(arr("part_w"), arr("part_b"), ints("K"), ints("N"), ints("P"),
+                                                           arr("dw"), arr("db"), n, stream), "linear_wgrad_reduce_many")
+
+    def drop_deferred(self) -> None:
+        """(a walk that raised: nothing must survive into the next one)"""
+        self._deferred = []
 
     def draw_seed(self) -> int:
         """One 63-bit seed for the library's counter RNG from torch's CPU generator (reproducible under

@@ -127,7 +127,7 @@ class _FusedLayerTail(torch.autograd.Function):
             two = lambda t: t.reshape(-1, t.shape[-1])
             c_rows = two(c) if pick is None else c.gather(1, pick.unsqueeze(-1).expand(-1, -1, H)).view(-1, H)
             (gwd, gbd), (gw1, gb1), (gw2, gb2) = ops.linear_wgrad_grouped(
-                [(c_rows, d_h1, True), (two(a), d_h2, True), (act, d_h3, True)])
+                [(c_rows, d_h1, True), (two(a), d_h2, True), (act, d_h3, True)], ctx.state)
             gb = ops.sum_rows(part, 0).view(4, H)  # (dgamma1, dbeta1, dgamma2, dbeta2)
             grads = [gwd, gbd, gb[0], gb[1], gw1, gb1, gw2, gb2, gb[2], gb[3]]
         return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None, None, None)
@@ -175,7 +175,7 @@ class _LayerTail(torch.autograd.Function):
         grads = [None] * 10  # wd, bd, g1, b1, w1, bb1, w2, bb2, g2, b2
         if params:
             (gwd, gbd), (gw1, gb1), (gw2, gb2) = ops.linear_wgrad_grouped(
-                [(two(c), two(d_h1), True), (two(a), two(d_h2), True), (two(act), two(d_h3), True)])
+                [(two(c), two(d_h1), True), (two(a), two(d_h2), True), (two(act), two(d_h3), True)], ctx.state)
             gb = ops.sum_rows(torch.stack((part1, part2)), 1)  # [2 norms, (dgamma, dbeta), H] in one pass
             grads = [gwd, gbd, gb[0, 0], gb[0, 1], gw1, gb1, gw2, gb2, gb[1, 0], gb[1, 1]]
         return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None, None)

@@ -51,6 +51,9 @@ class AttackSASRecTrainer:
         # the step state the model's autograd nodes read (which backward pass is running, replay seed counter);
         # owned by the model so that two trainers / models in one process stay independent
         self.state = getattr(model, 'step_state', None) or StepState().attach(model)
+        # weight-gradient reductions of a walk in one launch at its end (state.py): needs every leaf's .grad to START the walk
+        # as None, i.e. not the synchronizer's accumulate-in-place mode
+        self.state.defer_reductions = grad_sync is None or not grad_sync.in_place
         self.optimizer = self._build_optimizer()
         self._graph = None
         for name, module in model.named_modules():  # lets the linear layers skip discarded gradients in pass 2
@@ -111,15 +114,23 @@ class AttackSASRecTrainer:
         # requires_grad, then walks the WHOLE graph twice (frozen leaves just drop what reaches them).
         # `backward(inputs=...)` accumulates into exactly the same leaves with the same values, and lets
         # autograd skip the branches that only feed frozen leaves (weight-gradient GEMMs, embedding scatter).
-        with self.state.calibrated_pass():
-            calibrated_loss.backward(self._root(calibrated_loss), retain_graph=attacked_loss is not None, inputs=self._others)
+        try:
+            with self.state.calibrated_pass():
+                calibrated_loss.backward(self._root(calibrated_loss), retain_graph=attacked_loss is not None, inputs=self._others)
+            self.state.flush_deferred(self._others)  # the walk's weight-gradient reductions, one launch (state.py)
+        finally:
+            self.state.drop_deferred()
         return attacked_loss, calibrated_loss
 
     def _pass_two(self, attacked_loss):
         """Backward pass 2 (trainer.py:678-684): only the attack transforms accumulate."""
         if attacked_loss is not None:
-            with self.state.attack_pass():
-                attacked_loss.backward(self._root(attacked_loss), inputs=self._attack)
+            try:
+                with self.state.attack_pass():
+                    attacked_loss.backward(self._root(attacked_loss), inputs=self._attack)
+                self.state.flush_deferred(self._attack)
+            finally:
+                self.state.drop_deferred()
 
     def _forward(self, interaction, check_nan: bool = False):
         if self._seed_t is not None and not self._fused_inputs:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ACATTN_ABI_VERSION 28
+#define ACATTN_ABI_VERSION 29
 
 /* attention-mask encodings (recbole/model/abstract_recommender.py:136-143 builds the dense form) */
 enum {
@@ -386,6 +386,19 @@ int acattn_linear_wgrad(const float* x, const float* dy, int64_t M, int32_t K, i
 int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, const int32_t* K, const int32_t* N,
                                 float* const* dw, float* const* db, int32_t n_items, int64_t M, void* workspace,
                                 void* stream);
+
+/* [ABI 29] The two stages of acattn_linear_wgrad_grouped separately.  A training step has one stage-2 launch per layer and
+ * walk -- six 6-us launches at the benchmark shape for results that only the optimizer reads.  A trainer can launch stage 1
+ * where the gradient is due (`_partial`: the items' partial sums go to `workspace`; `n_partials` and, per item, the offsets
+ * in floats of its weight / bias partials inside `workspace` come back; want_bias[i] != 0 = bias partials wanted) and ONE
+ * stage 2 for all of them when the backward walk is over (`_reduce_many`: up to ACATTN_WGRAD_MAX_REDUCE items, each with its
+ * own partial pointers, sizes and partial count; db[i] may be NULL).  The workspaces must stay untouched in between. */
+#define ACATTN_WGRAD_MAX_REDUCE 32
+int acattn_linear_wgrad_grouped_partial(const float* const* x, const float* const* dy, const int32_t* K, const int32_t* N,
+                                        const int32_t* want_bias, int32_t n_items, int64_t M, void* workspace, int32_t* n_partials,
+                                        int64_t* w_offset, int64_t* b_offset, void* stream);
+int acattn_linear_wgrad_reduce_many(const float* const* part_w, const float* const* part_b, const int32_t* K, const int32_t* N,
+                                    const int32_t* n_partials, float* const* dw, float* const* db, int32_t n_items, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * The position-wise tail of one branch of an encoder layer in one launch (forward) / one launch (input gradients):
