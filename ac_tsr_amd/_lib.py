@@ -129,6 +129,7 @@ EMBED_BWD_CHUNKS = 8
 PENALTY_WS_FLOATS = 1024
 WGRAD_MAX_GROUP = 8
 WGRAD_MAX_REDUCE = 32
+SUMROWS_MAX_DEFER = 8
 
 # name -> (restype, argtypes); must list every symbol include/acattn.h declares (tests check this)
 SYMBOLS = {
@@ -188,7 +189,8 @@ SYMBOLS = {
     "acattn_linear_wgrad_grouped_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acattn_linear_wgrad_reduce_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                   C.c_void_p, C.c_int32, C.c_void_p]),
+                                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_int32, C.c_void_p]),
     "acattn_select_forward_kernel": (C.c_int, [C.c_int]),
     "acattn_select_backward_kernel": (C.c_int, [C.c_int]),
     "acattn_calibrated_attention_bwd_workspace_bytes": (C.c_int64, [C.POINTER(Problem)]),

@@ -542,16 +542,24 @@ int acattn_linear_wgrad_grouped_partial(const float* const* x, const float* cons
 }
 
 int acattn_linear_wgrad_reduce_many(const float* const* part_w, const float* const* part_b, const int32_t* K, const int32_t* N,
-                                    const int32_t* n_partials, float* const* dw, float* const* db, int32_t n_items, void* stream) {
-  if (!part_w || !part_b || !K || !N || !n_partials || !dw || !db) return fail("every array must be non-NULL");
-  if (n_items < 1 || n_items > ACATTN_WGRAD_MAX_REDUCE) return fail("n_items must lie in [1, ACATTN_WGRAD_MAX_REDUCE]");
+                                    const int32_t* n_partials, float* const* dw, float* const* db, int32_t n_items,
+                                    const float* const* sum_x, float* const* sum_out, const int32_t* sum_R, const int32_t* sum_C,
+                                    int32_t n_sums, void* stream) {
+  if (n_items < 0 || n_items > ACATTN_WGRAD_MAX_REDUCE) return fail("n_items must lie in [0, ACATTN_WGRAD_MAX_REDUCE]");
+  if (n_sums < 0 || n_sums > ACATTN_SUMROWS_MAX_DEFER) return fail("n_sums must lie in [0, ACATTN_SUMROWS_MAX_DEFER]");
+  if (n_items + n_sums < 1) return fail("nothing to reduce");
+  if (n_items > 0 && (!part_w || !part_b || !K || !N || !n_partials || !dw || !db)) return fail("every weight-gradient array must be non-NULL");
+  if (n_sums > 0 && (!sum_x || !sum_out || !sum_R || !sum_C)) return fail("every row-sum array must be non-NULL");
+  for (int i = 0; i < n_sums; ++i)
+    if (!sum_x[i] || !sum_out[i] || sum_R[i] < 1 || sum_C[i] < 1) return fail("every row sum needs x, out and positive sizes");
   for (int i = 0; i < n_items; ++i) {
     if (!part_w[i] || !dw[i]) return fail("every item needs its partials and dw");
     if (db[i] && !part_b[i]) return fail("db given without bias partials");
     if (K[i] < 1 || N[i] < 1 || n_partials[i] < 1) return fail("K, N and n_partials must be positive");
   }
   const int rc = acattn_launch_linear_wgrad_reduce_many(part_w, part_b, (const int*)K, (const int*)N, (const int*)n_partials, dw, db,
-                                                        n_items, (hipStream_t)stream);
+                                                        n_items, sum_x, sum_out, (const int*)sum_R, (const int*)sum_C, n_sums,
+                                                        (hipStream_t)stream);
   if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
   return rc;
 }

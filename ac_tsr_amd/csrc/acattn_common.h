@@ -357,7 +357,9 @@ int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, co
                                float* const* dw, float* const* db, int n_items, int64_t M, void* ws, hipStream_t stream,
                                int* P_out = nullptr, long long* w_off_out = nullptr, long long* b_off_out = nullptr);
 int acattn_launch_linear_wgrad_reduce_many(const float* const* part_w, const float* const* part_b, const int* K, const int* N,
-                                           const int* P, float* const* dw, float* const* db, int n_items, hipStream_t stream);
+                                           const int* P, float* const* dw, float* const* db, int n_items,
+                                           const float* const* sr_x, float* const* sr_out, const int* sr_R, const int* sr_C,
+                                           int n_sr, hipStream_t stream);
 int acattn_launch_embed_fwd(const acattn_embed_problem& p, float* y, float* stats, hipStream_t stream);
 int acattn_launch_embed_bwd(const acattn_embed_problem& p, const float* dy, const float* stats, int64_t padding_idx,
                             float* d_table, float* d_pos_part, float* dgb_part, hipStream_t stream);

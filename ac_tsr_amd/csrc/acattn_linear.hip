@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "acattn_common.h"
+#include "acattn_sumrows.h"
 
 namespace {
 
@@ -239,9 +240,19 @@ struct WgradMany {
   int K[ACATTN_WGRAD_MAX_REDUCE];
   int N[ACATTN_WGRAD_MAX_REDUCE];
   int P[ACATTN_WGRAD_MAX_REDUCE];
+  // ... and plain row sums out[c] = sum_r x[r, c] of the same walk (LayerNorm / calibrator parameter partials), as further
+  // z-slices of the launch: blockIdx.z >= n_w
+  SumRowsJob sr[ACATTN_SUMROWS_MAX_DEFER];
+  int n_w;
 };
 
 __global__ void __launch_bounds__(256) wgrad_reduce_many_kernel(const WgradMany G) {
+  if ((int)blockIdx.z >= G.n_w) {  // (uniform per workgroup)
+    const SumRowsJob& j = G.sr[blockIdx.z - G.n_w];
+    const int w = blockIdx.y * gridDim.x + blockIdx.x;
+    if (w < j.n_wg) sum_rows_block<false>(j.x, j.out, j.R, j.C, j.R, j.CT, w % j.col_groups, 0, w / j.col_groups);
+    return;
+  }
   const int it = blockIdx.z;
   const int K = G.K[it], N = G.N[it];
   const int KB = (K + 63) >> 6, NB = (N + 63) >> 6;
@@ -369,9 +380,16 @@ int acattn_launch_linear_wgrad(const float* const* x, const float* const* dy, co
 }
 
 int acattn_launch_linear_wgrad_reduce_many(const float* const* part_w, const float* const* part_b, const int* K, const int* N,
-                                           const int* P, float* const* dw, float* const* db, int n_items, hipStream_t stream) {
+                                           const int* P, float* const* dw, float* const* db, int n_items,
+                                           const float* const* sr_x, float* const* sr_out, const int* sr_R, const int* sr_C,
+                                           int n_sr, hipStream_t stream) {
   WgradMany G{};
+  G.n_w = n_items;
   int blocks = 1;
+  for (int i = 0; i < n_sr; ++i) {
+    G.sr[i] = make_job(sr_x[i], sr_out[i], 1, sr_R[i], sr_C[i]);
+    blocks = std::max(blocks, (G.sr[i].n_wg + kRegs * 2 - 1) / (kRegs * 2));
+  }
   for (int i = 0; i < n_items; ++i) {
     G.part_w[i] = part_w[i];
     G.part_b[i] = part_b[i];
@@ -382,6 +400,6 @@ int acattn_launch_linear_wgrad_reduce_many(const float* const* part_w, const flo
     G.P[i] = P[i];
     blocks = std::max(blocks, ((K[i] + 63) / 64) * ((N[i] + 63) / 64));
   }
-  hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(kRegs * 2, blocks, n_items), dim3(256), 0, stream, G);
+  hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(kRegs * 2, blocks, n_items + n_sr), dim3(256), 0, stream, G);
   return (int)hipGetLastError();
 }

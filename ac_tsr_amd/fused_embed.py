@@ -91,8 +91,11 @@ class _EmbedLayerNorm(torch.autograd.Function):
             d_pos[:L] = ops.sum_rows(pos_part, 0)
         dgamma = dbeta = None
         if want_gb:
-            gb = ops.sum_rows(gb_part, 0)
+            st = getattr(ctx, "state", None)
+            gb = ops.sum_rows0(gb_part, st)
             dgamma, dbeta = gb[0], gb[1]
+            if st is not None:
+                st.watch(gb, dgamma if ctx.needs_input_grad[3] else None, dbeta if ctx.needs_input_grad[4] else None)
         return None, (None if handed is not None else d_table), d_pos, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

@@ -289,7 +289,7 @@ class _CalibratedAttention(torch.autograd.Function):
                 wd.contiguous(), b_dist, scalar, nh, float(ctx.p_drop), int(ctx.seed) & 0x7FFFFFFFFFFFFFFF, ctx.seed_tensor,
                 bool(ctx.gate_is_prob), M, stats, d_att, d_cal, d_M, ctx.read_rows, ctx.active_qblocks, bool(attack_only), d_pen)
             return _CalibratedAttention._finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh,
-                                                         w_order, b_order, w_dist, b_dist, scalar, rich_ratio)
+                                                         w_order, b_order, w_dist, b_dist, scalar, rich_ratio, ctx.state)
         prob = _fill_problem(q, k, v, qa, ka, gate_logits, ctx.mask, wo, b_order, wd, b_dist, scalar, rich_ratio, cfg,
                              ctx.p_drop, ctx.rnd, ctx.seed, keep, ctx.seed_tensor, ctx.gate_is_prob)
         io = BwdIO()
@@ -324,7 +324,7 @@ class _CalibratedAttention(torch.autograd.Function):
             io.dgate_logits, io.dgate_summed = _ptr(dgate_part), int(summed)
         _lib.check(lib.acattn_calibrated_attention_bwd(C.byref(prob), C.byref(io), _stream()), "calibrated_attention_bwd")
         return _CalibratedAttention._finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh, w_order,
-                                                     b_order, w_dist, b_dist, scalar, rich_ratio)
+                                                     b_order, w_dist, b_dist, scalar, rich_ratio, ctx.state)
 
     @staticmethod
     def backward_pair(ctx, g_cal, g_att):
@@ -378,7 +378,7 @@ class _CalibratedAttention(torch.autograd.Function):
 
     @staticmethod
     def _finish_backward(lib, attack_only, dq, dk, dv, dqa, dka, dgate_part, part, dh, w_order, b_order, w_dist, b_dist,
-                         scalar, rich_ratio):
+                         scalar, rich_ratio, state=None):
         """The reductions behind the backward launch: per-head gate partials and per-(b, head) parameter partials."""
         dgate = None
         if attack_only:
@@ -395,7 +395,7 @@ class _CalibratedAttention(torch.autograd.Function):
         else:
             if dgate_part is not None:  # (one head, or the one-row form's head-summed tensor: nothing to add)
                 dgate = dgate_part[:, 0] if dgate_part.shape[1] == 1 else sum_rows(dgate_part, 1)
-            tot = sum_rows(part, 0)
+            tot = sum_rows(part, 0)  # (not deferred: these gradients pass through further nodes before they reach their leaves, so autograd does not adopt the tensors)
         small = tot[4 * dh:]
         g_wo = tot[:2 * dh].view_as(w_order) if w_order is not None else None
         g_bo = small[0:1].view_as(b_order) if w_order is not None else None
@@ -495,6 +495,18 @@ def sum_rows(x: torch.Tensor, dim: int = 0) -> torch.Tensor:
             part = _launch_sum_rows(x, batch * s, R // s, Cn, (batch, s, Cn))
             return _launch_sum_rows(part, batch, s, Cn, out_shape)
     return _launch_sum_rows(x, batch, R, Cn, out_shape)
+
+
+def sum_rows0(x: torch.Tensor, state=None) -> torch.Tensor:
+    """sum_rows(x, 0) of a parameter-partials tensor.  Inside a trainer's backward walk (`state.deferring()`) the sum is
+    left to the walk's one reduction launch: the tensor comes back unwritten and the caller names the views of it that it
+    returns as gradients with state.watch(...) (state.py)."""
+    if state is not None and state.deferring() and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[0] > 1:
+        x = x.contiguous()
+        out = torch.empty(x.shape[1:], device=x.device, dtype=torch.float32)
+        state.defer_sum(x, out)
+        return out
+    return sum_rows(x, 0)
 
 
 def linear_wgrad(x2: torch.Tensor, g2: torch.Tensor, want_bias: bool, state=None):

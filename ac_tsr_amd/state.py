@@ -193,6 +193,18 @@ class StepState:
     def defer(self, job) -> None:
         self._deferred.append(job)
 
+    def defer_sum(self, x: torch.Tensor, out: torch.Tensor) -> None:
+        """out[c] = sum_r x[r, c], written by flush_deferred().  The caller hands autograd VIEWS of `out` and names them with
+        watch() right behind: those are what has to be adopted."""
+        self._deferred.append({"sum_x": x.data_ptr(), "sum_out": out.data_ptr(), "R": x.shape[0], "C": x.numel() // x.shape[0],
+                               "watch": [], "keep": (x.untyped_storage(), out.untyped_storage())})
+
+    def watch(self, out: torch.Tensor, *views) -> None:
+        """The gradient tensors (views of `out`) that autograd must adopt -- if `out` is the last defer_sum's (ops.sum_rows0
+        may have summed on the spot)."""
+        if self._deferred and self._deferred[-1].get("sum_out") == out.data_ptr():
+            self._deferred[-1]["watch"] += [v.data_ptr() for v in views if v is not None]
+
     def flush_deferred(self, params) -> None:
         """End of a backward walk over the leaves `params`: one stage-2 launch per ACATTN_WGRAD_MAX_REDUCE queued items.
         Every queued destination must by now BE the .grad of one of `params` (same memory): anything else means autograd
@@ -204,19 +216,23 @@ class StepState:
         from . import _lib
         owned = {p.grad.data_ptr() for p in params if p.grad is not None}
         for j in jobs:
-            for ptr in (j["dw"], j["db"]):
+            for k, ptr in enumerate((j["dw"], j["db"]) if "dw" in j else j["watch"]):
                 if ptr is not None and ptr not in owned:
-                    raise RuntimeError("a deferred weight gradient was not adopted by autograd as the parameter's .grad "
-                                       "(ACATTN_NO_DEFER=1 switches the deferral off)")
+                    what = (f"weight gradient [{j['N']}, {j['K']}]" if "dw" in j else f"row sum [{j['R']}, {j['C']}]") + f", output {k}"
+                    raise RuntimeError(f"a deferred parameter gradient ({what}) was not adopted by autograd as the parameter's "
+                                       ".grad (ACATTN_NO_DEFER=1 switches the deferral off)")
         lib = _lib.load()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for s0 in range(0, len(jobs), _lib.WGRAD_MAX_REDUCE):
-            chunk = jobs[s0:s0 + _lib.WGRAD_MAX_REDUCE]
-            n = len(chunk)
-            arr = lambda key: (C.c_void_p * n)(*(j[key] for j in chunk))
-            ints = lambda key: (C.c_int32 * n)(*(j[key] for j in chunk))
-            _lib.check(lib.acattn_linear_wgrad_reduce_many(arr("part_w"), arr("part_b"), ints("K"), ints("N"), ints("P"),
-                                                           arr("dw"), arr("db"), n, stream), "linear_wgrad_reduce_many")
+        wj = [j for j in jobs if "dw" in j]
+        sj = [j for j in jobs if "sum_x" in j]
+        while wj or sj:  # one launch per (ACATTN_WGRAD_MAX_REDUCE weight gradients + ACATTN_SUMROWS_MAX_DEFER row sums)
+            w, wj = wj[:_lib.WGRAD_MAX_REDUCE], wj[_lib.WGRAD_MAX_REDUCE:]
+            r, sj = sj[:_lib.SUMROWS_MAX_DEFER], sj[_lib.SUMROWS_MAX_DEFER:]
+            arr = lambda js, key: (C.c_void_p * max(1, len(js)))(*(j[key] for j in js))
+            ints = lambda js, key: (C.c_int32 * max(1, len(js)))(*(j[key] for j in js))
+            _lib.check(lib.acattn_linear_wgrad_reduce_many(arr(w, "part_w"), arr(w, "part_b"), ints(w, "K"), ints(w, "N"), ints(w, "P"),
+                                                           arr(w, "dw"), arr(w, "db"), len(w), arr(r, "sum_x"), arr(r, "sum_out"),
+                                                           ints(r, "R"), ints(r, "C"), len(r), stream), "linear_wgrad_reduce_many")
 
     def drop_deferred(self) -> None:
         """(a walk that raised: nothing must survive into the next one)"""

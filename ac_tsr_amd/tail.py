@@ -128,8 +128,9 @@ class _FusedLayerTail(torch.autograd.Function):
             c_rows = two(c) if pick is None else c.gather(1, pick.unsqueeze(-1).expand(-1, -1, H)).view(-1, H)
             (gwd, gbd), (gw1, gb1), (gw2, gb2) = ops.linear_wgrad_grouped(
                 [(c_rows, d_h1, True), (two(a), d_h2, True), (act, d_h3, True)], ctx.state)
-            gb = ops.sum_rows(part, 0).view(4, H)  # (dgamma1, dbeta1, dgamma2, dbeta2)
+            gb = ops.sum_rows0(part, ctx.state).view(4, H)  # (dgamma1, dbeta1, dgamma2, dbeta2)
             grads = [gwd, gbd, gb[0], gb[1], gw1, gb1, gw2, gb2, gb[2], gb[3]]
+            ctx.state.watch(gb, grads[2], grads[3], grads[8], grads[9])
         return (d_c, d_x, *grads, None, None, None, None, None, None, None, None, None, None, None)
 
 

@@ -392,13 +392,19 @@ int acattn_linear_wgrad_grouped(const float* const* x, const float* const* dy, c
  * where the gradient is due (`_partial`: the items' partial sums go to `workspace`; `n_partials` and, per item, the offsets
  * in floats of its weight / bias partials inside `workspace` come back; want_bias[i] != 0 = bias partials wanted) and ONE
  * stage 2 for all of them when the backward walk is over (`_reduce_many`: up to ACATTN_WGRAD_MAX_REDUCE items, each with its
- * own partial pointers, sizes and partial count; db[i] may be NULL).  The workspaces must stay untouched in between. */
+ * own partial pointers, sizes and partial count; db[i] may be NULL) -- which also takes up to ACATTN_SUMROWS_MAX_DEFER plain
+ * row sums sum_out[i][c] = sum_r sum_x[i][r, c] (sum_x[i] contiguous [sum_R[i], sum_C[i]]: the LayerNorm / calibrator
+ * parameter partials of the same walk, acattn_sum_rows with batch 1) as further slices of the same launch; either list may
+ * be empty.  The workspaces must stay untouched in between. */
 #define ACATTN_WGRAD_MAX_REDUCE 32
+#define ACATTN_SUMROWS_MAX_DEFER 8
 int acattn_linear_wgrad_grouped_partial(const float* const* x, const float* const* dy, const int32_t* K, const int32_t* N,
                                         const int32_t* want_bias, int32_t n_items, int64_t M, void* workspace, int32_t* n_partials,
                                         int64_t* w_offset, int64_t* b_offset, void* stream);
 int acattn_linear_wgrad_reduce_many(const float* const* part_w, const float* const* part_b, const int32_t* K, const int32_t* N,
-                                    const int32_t* n_partials, float* const* dw, float* const* db, int32_t n_items, void* stream);
+                                    const int32_t* n_partials, float* const* dw, float* const* db, int32_t n_items,
+                                    const float* const* sum_x, float* const* sum_out, const int32_t* sum_R, const int32_t* sum_C,
+                                    int32_t n_sums, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * The position-wise tail of one branch of an encoder layer in one launch (forward) / one launch (input gradients):

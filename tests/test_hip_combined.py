@@ -164,3 +164,51 @@ def test_one_walk_equals_two_walks_on_the_less_common_paths(over):
     for n in grads[0]:
         scale = grads[0][n].abs().max().item()
         assert (grads[0][n] - grads[1][n]).abs().max().item() <= 1e-4 * scale + 1e-8, n
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+@pytest.mark.parametrize("L,H,nh", [(50, 64, 2), (200, 128, 4)], ids=["headline_shape", "cfg4_shape"])
+def test_deferred_weight_gradient_reductions_change_nothing(graph, L, H, nh):
+    """[r4] StepState.defer_reductions (the trainer's default): stage 2 of every weight gradient and the LayerNorm parameter
+    sums of a backward walk in ONE launch at its end, written into the tensors autograd adopted as the leaves' .grad.  The
+    same kernels sum in the same order; three optimizer steps must leave the same parameters up to the run-to-run noise of
+    the step's float atomics (embedding scatter, the cross-entropy's one-hot rows) -- and the deferred path must have been
+    the one that ran."""
+    from ac_tsr_amd.state import StepState
+    g = torch.Generator().manual_seed(2)
+    B, N = 40, 2500
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    ids = torch.randint(1, N, (B, L), generator=g) * (torch.arange(L)[None] < lens[:, None])
+    batch = {"item_id_list": ids.to(DEV), "item_length": lens.to(DEV), "item_id": ids[torch.arange(B), lens - 1].to(DEV)}
+    states, flushed = [], []
+    for defer in (False, True):
+        torch.manual_seed(3)
+        model = A.ACSASRec(A.DictConfig(_cfgd(hidden_size=H, n_heads=nh, inner_size=4 * H, MAX_ITEM_LIST_LENGTH=L,
+                                              gate_seq_length=L)), A.ItemCount(N)).to(DEV)
+        trainer = A.AttackSASRecTrainer(A.DictConfig(learner='adam', learning_rate=1e-3), model)
+        assert trainer.state.defer_reductions  # the default
+        trainer.state.defer_reductions = defer
+        n_jobs = []
+        orig = StepState.flush_deferred
+
+        def counting(self, params, _orig=orig, _n=n_jobs):
+            _n.append(len(self._deferred))
+            return _orig(self, params)
+
+        StepState.flush_deferred = counting
+        try:
+            model.train()
+            torch.manual_seed(5)
+            if graph:
+                trainer.enable_graph(batch, warmup=1)
+            for _ in range(3):
+                trainer.train_step(batch)
+            torch.cuda.synchronize()
+        finally:
+            StepState.flush_deferred = orig
+        flushed.append(sum(n_jobs))
+        states.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    assert flushed[0] == 0 and flushed[1] >= 10, flushed  # (projections: 5-6 weights per layer, tails: 3 + a row sum)
+    for k in states[0]:
+        scale = max(1e-3, states[0][k].abs().max().item())
+        assert (states[0][k] - states[1][k]).abs().max().item() <= 2e-5 * scale + 2e-7, k
