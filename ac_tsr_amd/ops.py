@@ -395,7 +395,11 @@ class _CalibratedAttention(torch.autograd.Function):
         else:
             if dgate_part is not None:  # (one head, or the one-row form's head-summed tensor: nothing to add)
                 dgate = dgate_part[:, 0] if dgate_part.shape[1] == 1 else sum_rows(dgate_part, 1)
-            tot = sum_rows(part, 0)  # (not deferred: these gradients pass through further nodes before they reach their leaves, so autograd does not adopt the tensors)
+            if state is not None and state.attack_pass_only:
+                # pass 2 keeps only the attack transforms' gradients (trainer.py:678-684): the calibrators' are dropped by
+                # autograd on arrival, so they are not summed at all
+                return (dq, dk, dv, dqa, dka, dgate) + (None,) * 18
+            tot = sum_rows0(part, state)
         small = tot[4 * dh:]
         g_wo = tot[:2 * dh].view_as(w_order) if w_order is not None else None
         g_bo = small[0:1].view_as(b_order) if w_order is not None else None
@@ -403,6 +407,8 @@ class _CalibratedAttention(torch.autograd.Function):
         g_bd = small[1:2].view_as(b_dist) if w_dist is not None else None
         g_sc = small[2:3].view_as(scalar) if w_dist is not None else None
         g_rr = small[3:4].view_as(rich_ratio) if rich_ratio is not None else None
+        if state is not None:
+            state.watch(tot, g_wo, g_bo, g_wd, g_bd, g_sc, g_rr)
         return (dq, dk, dv, dqa, dka, dgate, g_wo, g_bo, g_wd, g_bd, g_sc, g_rr, None, None, None, None, None, None, None,
                 None, None, None, None, None)
 
