@@ -25,7 +25,7 @@ _NO_DEFER = _os.environ.get("ACATTN_NO_DEFER") == "1"  # measurement / bisection
 
 class StepState:
     __slots__ = ("pass_mode", "seed_tensor", "prune_dead_work", "seed_salt", "tick", "table_grad", "grad_home", "_frozen",
-                 "_home_claimed", "affine_ws", "combined", "defer_reductions", "_deferred")
+                 "_home_claimed", "affine_ws", "combined", "defer_reductions", "_deferred", "_flush_leaves")
 
     def __init__(self, frozen: bool = False):
         object.__setattr__(self, "_frozen", False)
@@ -70,9 +70,11 @@ class StepState:
         # ~6 us per step become two).  Sound only because (a) nothing reads a parameter gradient before the walk ends,
         # (b) autograd ADOPTS the tensor it is handed for a leaf whose .grad is None (AccumulateGrad's use_count test:
         # the queue keeps the storage alive, not the tensor) -- flush_deferred verifies (b) for every job and raises
-        # otherwise.  Set by the trainer (AttackSASRecTrainer); off anywhere else.
+        # otherwise.  Set by the trainer (AttackSASRecTrainer), which opens its passes with the walk's leaves
+        # (calibrated_pass(leaves) / attack_pass(leaves)): the pass context itself flushes at its end.  Off anywhere else.
         self.defer_reductions = False
         self._deferred = []
+        self._flush_leaves = None
         object.__setattr__(self, "_frozen", frozen)
 
     def __setattr__(self, name, value):
@@ -95,6 +97,7 @@ class StepState:
         self.combined = None
         self.defer_reductions = False
         self._deferred = []
+        self._flush_leaves = None
         object.__setattr__(self, "_frozen", st["frozen"])
 
     def __copy__(self):
@@ -124,23 +127,36 @@ class StepState:
         return self.pass_mode == "calibrated"
 
     @contextmanager
-    def _pass(self, mode):
-        prev = self.pass_mode
+    def _pass(self, mode, leaves=None):
+        prev, prev_leaves = self.pass_mode, self._flush_leaves
         self.pass_mode = mode
         self.table_grad = None  # a new walk: nothing published, no flat-buffer home handed out yet
         self._home_claimed = None
+        # reductions are deferred only inside a pass that was opened WITH the leaves of its walk: that pass flushes them when
+        # it ends, so no caller can be left holding unwritten gradients
+        self._flush_leaves = list(leaves) if (leaves is not None and self.defer_reductions) else None
+        self._deferred = []
+        ok = False
         try:
             yield self
+            ok = True
         finally:
-            self.pass_mode = prev
+            try:
+                if ok and self._flush_leaves is not None:
+                    self.flush_deferred(self._flush_leaves)
+            finally:
+                self._deferred = []
+                self.pass_mode, self._flush_leaves = prev, prev_leaves
 
-    def calibrated_pass(self):
-        """Inside: layers tagged `_acattn_attack = True` produce no parameter gradients."""
-        return self._pass("calibrated")
+    def calibrated_pass(self, leaves=None):
+        """Inside: layers tagged `_acattn_attack = True` produce no parameter gradients.  `leaves`: the parameters the walk
+        inside accumulates into (backward(inputs=leaves)) -- given, parameter-gradient reductions may be deferred to the
+        end of the pass (defer_reductions)."""
+        return self._pass("calibrated", leaves)
 
-    def attack_pass(self):
-        """Inside: only layers tagged `_acattn_attack = True` produce parameter gradients."""
-        return self._pass("attack")
+    def attack_pass(self, leaves=None):
+        """Inside: only layers tagged `_acattn_attack = True` produce parameter gradients.  `leaves` as in calibrated_pass."""
+        return self._pass("attack", leaves)
 
     def next_tick(self) -> int:
         """Forward-order stamp of an autograd node (-1 on the frozen default: no hand-over there)."""
@@ -187,7 +203,7 @@ class StepState:
     # ---- deferred weight-gradient reductions (see __init__) ------------------------------------------------------------
     def deferring(self) -> bool:
         """May a node of the walk that is running leave its stage-2 reduction to flush_deferred()?"""
-        return (not self._frozen and self.defer_reductions and self.combined is None
+        return (not self._frozen and self.defer_reductions and self.combined is None and self._flush_leaves is not None
                 and self.pass_mode in ("calibrated", "attack") and not _NO_DEFER)
 
     def defer(self, job) -> None:
@@ -233,10 +249,6 @@ class StepState:
             _lib.check(lib.acattn_linear_wgrad_reduce_many(arr(w, "part_w"), arr(w, "part_b"), ints(w, "K"), ints(w, "N"), ints(w, "P"),
                                                            arr(w, "dw"), arr(w, "db"), len(w), arr(r, "sum_x"), arr(r, "sum_out"),
                                                            ints(r, "R"), ints(r, "C"), len(r), stream), "linear_wgrad_reduce_many")
-
-    def drop_deferred(self) -> None:
-        """(a walk that raised: nothing must survive into the next one)"""
-        self._deferred = []
 
     def draw_seed(self) -> int:
         """One 63-bit seed for the library's counter RNG from torch's CPU generator (reproducible under

@@ -114,23 +114,15 @@ class AttackSASRecTrainer:
         # requires_grad, then walks the WHOLE graph twice (frozen leaves just drop what reaches them).
         # `backward(inputs=...)` accumulates into exactly the same leaves with the same values, and lets
         # autograd skip the branches that only feed frozen leaves (weight-gradient GEMMs, embedding scatter).
-        try:
-            with self.state.calibrated_pass():
-                calibrated_loss.backward(self._root(calibrated_loss), retain_graph=attacked_loss is not None, inputs=self._others)
-            self.state.flush_deferred(self._others)  # the walk's weight-gradient reductions, one launch (state.py)
-        finally:
-            self.state.drop_deferred()
+        with self.state.calibrated_pass(self._others):  # (the pass ends with the walk's parameter-gradient reductions, one launch: state.py)
+            calibrated_loss.backward(self._root(calibrated_loss), retain_graph=attacked_loss is not None, inputs=self._others)
         return attacked_loss, calibrated_loss
 
     def _pass_two(self, attacked_loss):
         """Backward pass 2 (trainer.py:678-684): only the attack transforms accumulate."""
         if attacked_loss is not None:
-            try:
-                with self.state.attack_pass():
-                    attacked_loss.backward(self._root(attacked_loss), inputs=self._attack)
-                self.state.flush_deferred(self._attack)
-            finally:
-                self.state.drop_deferred()
+            with self.state.attack_pass(self._attack):
+                attacked_loss.backward(self._root(attacked_loss), inputs=self._attack)
 
     def _forward(self, interaction, check_nan: bool = False):
         if self._seed_t is not None and not self._fused_inputs:

@@ -193,7 +193,7 @@ def test_deferred_weight_gradient_reductions_change_nothing(graph, L, H, nh):
 
         def counting(self, params, _orig=orig, _n=n_jobs):
             _n.append(len(self._deferred))
-            return _orig(self, params)
+            return _orig(self, params)  # (called by the pass context the trainer opens with the walk's leaves)
 
         StepState.flush_deferred = counting
         try:
@@ -209,6 +209,12 @@ def test_deferred_weight_gradient_reductions_change_nothing(graph, L, H, nh):
         flushed.append(sum(n_jobs))
         states.append({k: v.detach().clone() for k, v in model.state_dict().items()})
     assert flushed[0] == 0 and flushed[1] >= 10, flushed  # (projections: 5-6 weights per layer, tails: 3 + a row sum)
+    # a pass opened WITHOUT the walk's leaves never defers: nobody would flush
+    st = trainer.state
+    with st.calibrated_pass():
+        assert not st.deferring()
+    with st.calibrated_pass([p for p in model.parameters()]):
+        assert st.deferring()
     for k in states[0]:
         scale = max(1e-3, states[0][k].abs().max().item())
         assert (states[0][k] - states[1][k]).abs().max().item() <= 2e-5 * scale + 2e-7, k
