@@ -180,6 +180,7 @@ SYMBOLS = {
     "acattn_attacked_loss_finish_rows": (C.c_int, [_f, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _f, _f, C.c_int32,
                                                   C.c_void_p]),
     "acattn_mask_penalty_drows": (C.c_int, [_f, _f, C.c_float, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "acattn_mask_penalty_drows_dir": (C.c_int, [_f, _f, C.c_float, C.c_int32, C.c_void_p, C.c_int32, _f, _f, C.c_int32, C.c_void_p]),
     "acattn_mask_penalty_bwd_scaled": (C.c_int, [_f, _f, _f, C.c_float, C.c_int64, _f, C.c_void_p]),
     "acattn_mask_penalty_bwd": (C.c_int, [_f, _f, _f, C.c_int64, _f, C.c_void_p]),
     "acattn_linear_wgrad_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),

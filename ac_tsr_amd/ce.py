@@ -277,16 +277,22 @@ class _AttackedLossRows(torch.autograd.Function):
             d_out, d_table = torch.empty_like(out), (torch.empty_like(table) if want_table else None)
             _lib.check(lib.acattn_full_sort_ce_bwd(C.byref(p), _ptr(lse), _ptr(d_loss), _ptr(ws), _ptr(d_out), _ptr(d_table),
                                                    _stream()), "full_sort_ce_bwd")
+            from_dir = False
         else:
-            d_out = direction * d_loss  # direction already carries -1/B
+            d_out = torch.empty_like(direction)  # = direction * d_loss (direction already carries -1/B), in the launch below
+            from_dir = True
         n = len(ctx.pen_shapes)
         count = 1
         for d in ctx.pen_shapes[0]:
             count *= d
         d_flat = torch.empty(n, count, device=out.device, dtype=torch.float32)  # every layer's vector in one launch
         dp = (C.c_void_p * n)(*(d_flat[l].data_ptr() for l in range(n)))
-        _lib.check(lib.acattn_mask_penalty_drows(_ptr(res[2:]), _ptr(d_loss), ctx.weight / n, count, dp, n, _stream()),
-                   "mask_penalty_drows")
+        if from_dir:
+            _lib.check(lib.acattn_mask_penalty_drows_dir(_ptr(res[2:]), _ptr(d_loss), ctx.weight / n, count, dp, n, _ptr(direction),
+                                                         _ptr(d_out), direction.numel(), _stream()), "mask_penalty_drows_dir")
+        else:
+            _lib.check(lib.acattn_mask_penalty_drows(_ptr(res[2:]), _ptr(d_loss), ctx.weight / n, count, dp, n, _stream()),
+                       "mask_penalty_drows")
         d_pens = [d_flat[l].view(ctx.pen_shapes[l]) if ctx.needs_input_grad[5 + l] else None for l in range(n)]
         return (d_out, d_table, None, None, None, *d_pens)
 

@@ -440,6 +440,17 @@ int acattn_mask_penalty_drows(const float* norms, const float* d_loss, float sca
   return rc;
 }
 
+int acattn_mask_penalty_drows_dir(const float* norms, const float* d_loss, float scale, int32_t count, float* const* d_pen,
+                                  int32_t n_masks, const float* direction, float* d_out, int32_t n_dir, void* stream) {
+  if (!norms || !d_loss || !d_pen || !direction || !d_out) return fail("norms, d_loss, d_pen, direction and d_out must be non-NULL");
+  if (count < 1 || n_dir < 1 || n_masks < 1 || n_masks > ACATTN_MAX_MASKS) return fail("count, n_dir positive, 1 <= n_masks <= ACATTN_MAX_MASKS");
+  for (int l = 0; l < n_masks; ++l)
+    if (!d_pen[l]) return fail("every d_pen vector must be non-NULL");
+  const int rc = acattn_launch_penalty_drows(norms, d_loss, scale, count, d_pen, n_masks, (hipStream_t)stream, direction, d_out, n_dir);
+  if (rc > 0) snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return rc;
+}
+
 int acattn_mask_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n, float* d_m,
                                    void* stream) {
   if (!m || !norm || !d_loss || !d_m) return fail("m, norm, d_loss and d_m must be non-NULL");

@@ -372,7 +372,7 @@ int acattn_launch_penalty_rows(const float* m, int B, int nh, int L, float* pen,
 int acattn_launch_attacked_loss_finish_rows(const float* row_loss, int B, const float* const* pen, int n_masks, int count,
                                             float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream);
 int acattn_launch_penalty_drows(const float* norms, const float* d_loss, float scale, int count, float* const* d_pen,
-                                int n_masks, hipStream_t stream);
+                                int n_masks, hipStream_t stream, const float* dir = nullptr, float* d_out = nullptr, int n_dir = 0);
 int acattn_launch_attacked_loss_finish(const float* row_loss, int B, const float* part, int n_masks, int64_t mask_numel,
                                        float weight, float* out, float* scale_buf, int n_scale, hipStream_t stream);
 int acattn_launch_penalty_bwd_scaled(const float* m, const float* norm, const float* d_loss, float scale, int64_t n,

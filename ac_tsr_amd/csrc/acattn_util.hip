@@ -306,9 +306,19 @@ __global__ void __launch_bounds__(256) attacked_loss_finish_rows_kernel(const fl
   }
 }
 
-// d_pen[l][:] = d_loss * scale / (2 norm_l)
+// d_pen[l][:] = d_loss * scale / (2 norm_l); slice blockIdx.y == n_masks (when launched): d_out[:] = dir[:] * d_loss, the
+// attacked loss's output cotangent from its saved direction in the same launch
 __global__ void __launch_bounds__(256) penalty_drows_kernel(const PenaltyRows R, const float* __restrict__ norms,
-                                                            const float* __restrict__ d_loss, const float scale, const int count) {
+                                                            const float* __restrict__ d_loss, const float scale, const int count,
+                                                            const int n_masks, const float* __restrict__ dir,
+                                                            float* __restrict__ d_out, const int n_dir) {
+  if ((int)blockIdx.y >= n_masks) {  // (uniform per workgroup)
+    const float k = d_loss[0];
+    const int n4 = ((reinterpret_cast<uintptr_t>(dir) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0 ? n_dir >> 2 : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) *(f4*)(d_out + 4 * i) = *(const f4*)(dir + 4 * i) * k;
+    for (int i = 4 * n4 + blockIdx.x * 256 + threadIdx.x; i < n_dir; i += gridDim.x * 256) d_out[i] = dir[i] * k;
+    return;
+  }
   const float nv = norms[blockIdx.y];
   const float k = nv > 0.f ? d_loss[0] * scale / (2.0f * nv) : 0.f;
   float* d = R.d_pen[blockIdx.y];
@@ -332,11 +342,13 @@ int acattn_launch_attacked_loss_finish_rows(const float* row_loss, int B, const 
 }
 
 int acattn_launch_penalty_drows(const float* norms, const float* d_loss, float scale, int count, float* const* d_pen,
-                                int n_masks, hipStream_t stream) {
+                                int n_masks, hipStream_t stream, const float* dir, float* d_out, int n_dir) {
   PenaltyRows R{};
   for (int l = 0; l < n_masks; ++l) R.d_pen[l] = d_pen[l];
-  hipLaunchKernelGGL(penalty_drows_kernel, dim3(std::max(1, std::min((count + 255) / 256, 64)), n_masks), dim3(256), 0, stream,
-                     R, norms, d_loss, scale, count);
+  const bool with_dir = dir && d_out && n_dir > 0;
+  const int gx = std::max(1, std::min((std::max(count, with_dir ? n_dir / 4 : 0) + 255) / 256, 64));
+  hipLaunchKernelGGL(penalty_drows_kernel, dim3(gx, n_masks + (with_dir ? 1 : 0)), dim3(256), 0, stream, R, norms, d_loss, scale,
+                     count, n_masks, dir, d_out, with_dir ? n_dir : 0);
   return (int)hipGetLastError();
 }
 

@@ -361,6 +361,10 @@ int acattn_attacked_loss_finish_rows(const float* row_loss, int32_t B, const flo
                                      float weight, float* out, float* scale_buf, int32_t n_scale, void* stream);
 int acattn_mask_penalty_drows(const float* norms, const float* d_loss, float scale, int32_t count, float* const* d_pen,
                               int32_t n_masks, void* stream);
+/* [ABI 29] acattn_mask_penalty_drows + d_out[:] = direction[:] * d_loss[0] (n_dir floats; the attacked loss's output
+ * cotangent from the direction acattn_full_sort_ce_fwd_dir saved, acsasrec.py:129-137) in the same launch. */
+int acattn_mask_penalty_drows_dir(const float* norms, const float* d_loss, float scale, int32_t count, float* const* d_pen,
+                                  int32_t n_masks, const float* direction, float* d_out, int32_t n_dir, void* stream);
 /* The same two for all masks of a model (one per layer, each of n elements, at most ACATTN_MAX_MASKS) in ONE launch each:
  * part [n_masks, ACATTN_PENALTY_WS_FLOATS]; norms [n_masks] (the out + 2 of acattn_attacked_loss_finish). */
 #define ACATTN_MAX_MASKS 8
