@@ -230,6 +230,70 @@ def kernel_roofline(a, device, adversarial=True, iters=300, nsets=None, full_len
             "avg_launch_us": round(best, 2), "launches_timed": 3 * iters, "buffer_sets": nsets}
 
 
+def ce_roofline(a, device, iters=40, nsets=3):
+    """The three sweeps of the full-catalogue cross-entropy (the largest block of the step: acsasrec.py:117-120) as the
+    training step launches them -- forward, forward with direction, backward with table gradient -- each entry point timed
+    with events over `iters` calls on `nsets` rotating (out, table) sets.  Matrix bound: `achieved` = the products'
+    ALGORITHMIC fp32 FLOPs (2 B N H per product; 1 / 2 / 3 products) over the average call, `peak` = the fp32 matrix
+    peak of MI355X_MICROARCH.md (157.3 TFLOP/s: what the exact-fp32 instruction could reach); `bf16_mfma_tflops` = the
+    bf16 matrix work actually issued (6 MFMAs per product at hidden 64 in the split-product mode) against 2,500."""
+    import ctypes as C
+    from ac_tsr_amd import _lib
+    lib = _lib.load()
+    B, N, H = a.batch, a.items, a.hidden
+    gen = torch.Generator().manual_seed(7)
+    sets = []
+    for s in range(nsets):
+        out = torch.randn(B, H, generator=gen).to(device)
+        table = (0.05 * torch.randn(N, H, generator=gen)).to(device)
+        target = torch.randint(1, N, (B,), generator=gen).to(device)
+        p = _lib.CeProblem()
+        p.B, p.N, p.H = B, N, H
+        p.out, p.table, p.target = out.data_ptr(), table.data_ptr(), target.data_ptr()
+        nbytes = lib.acattn_full_sort_ce_workspace_bytes(C.byref(p))
+        if nbytes < 0:
+            return None
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        lse, row_loss = torch.empty(B, device=device), torch.empty(B, device=device)
+        direction, d_out, d_table = torch.empty_like(out), torch.empty_like(out), torch.empty_like(table)
+        coef = torch.full((1,), 1.0, device=device)
+        pb = _lib.CeProblem()
+        pb.B, pb.N, pb.H, pb.out, pb.table, pb.target = B, N, H, p.out, p.table, p.target
+        pb.coef_is_scalar, pb.coef_scale = 1, 1.0 / B
+        sets.append((p, pb, ws, lse, row_loss, direction, d_out, d_table, coef, out, table, target))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    calls = {
+        "forward (acattn_full_sort_ce_fwd)": (1, lambda S: lib.acattn_full_sort_ce_fwd(C.byref(S[0]), ptr(S[2]), ptr(S[3]), ptr(S[4]), stream)),
+        "forward with direction (acattn_full_sort_ce_fwd_dir)": (2, lambda S: lib.acattn_full_sort_ce_fwd_dir(C.byref(S[0]), ptr(S[2]), ptr(S[3]), ptr(S[4]), ptr(S[5]), stream)),
+        "backward with table gradient (acattn_full_sort_ce_bwd)": (3, lambda S: lib.acattn_full_sort_ce_bwd(C.byref(S[1]), ptr(S[3]), ptr(S[8]), ptr(S[2]), ptr(S[6]), ptr(S[7]), stream)),
+    }
+    split = "split" in _ce_products_mode(a)
+    res = []
+    for name, (n_prod, fn) in calls.items():
+        for i in range(3):
+            _lib.check(fn(sets[i % nsets]), name)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            rc = fn(sets[i % nsets])
+            if rc:
+                _lib.check(rc, name)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        flops = 2.0 * B * N * H * n_prod
+        tf = flops / (us * 1e-6) / 1e12
+        res.append({"call": name, "avg_call_us": round(us, 1), "products": n_prod, "algorithmic_flops_per_call": int(flops),
+                    "bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 3),
+                    "bf16_mfma_tflops": round(6 * tf, 1) if split else None,
+                    "bf16_mfma_frac_of_2500": round(6 * tf / 2500.0, 3) if split else None})
+    return {"arithmetic": _ce_products_mode(a), "calls_timed": iters, "buffer_sets": nsets,
+            "note": "each call = its sweep + the small launches behind it (operand split of the batch rows, slab / partial folds)",
+            "sweeps": res}
+
+
 # --------------------------------------------------------------------------------------------------
 # the other shapes north_star / BASELINE.json name, a handful of steps each, appended to the default line
 # --------------------------------------------------------------------------------------------------
@@ -551,6 +615,11 @@ def main():
         # algorithmic bytes are the same, no key tile past the last item can be skipped
         res["roofline_full_length"] = kernel_roofline(a, device, True, a.kernel_iters, full_length=True)
         res["roofline_spatial_only"] = kernel_roofline(a, device, False, a.kernel_iters)
+        if a.model != "AcBERT4Rec":
+            try:
+                res["roofline_ce"] = ce_roofline(a, device)
+            except Exception as e:  # (an extra of the line: never the reason a bench run fails)
+                res["roofline_ce"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and a.config is None and not a.no_other_configs and (a.batch, a.seq_len, a.hidden, a.heads) == (512, 50, 64, 2):
             res["other_configs"] = other_configs(a, device)
         if world == 1 and not a.no_cpu_baseline and a.model == "ACSASRec":
