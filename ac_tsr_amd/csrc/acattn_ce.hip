@@ -866,7 +866,9 @@ template <int CH>
 bool ce6_plan(int N, int& n_wg, int& n_left) {
   if (CH != 64 || ce_products() == 0) return false;
   if (split_plan<CH>(N, n_wg, n_left)) return true;
-  if (ce_products() == 2 || pick_tiles<CH>(N) == 6) {
+  // ... and beyond: more than 65,536 items always fill the chip with six-tile waves, in 1.x or more rounds (200,000 items:
+  // 521 workgroups, three rounds of ~110 us against two seven-tile fp32 rounds of ~265)
+  if (ce_products() == 2 || pick_tiles<CH>(N) >= 6) {
     n_wg = (N + CE_NW * 96 - 1) / (CE_NW * 96);
     n_left = 0;
     return true;

@@ -38,8 +38,8 @@ def _ce_products_mode(a):
     if mode == 0:
         return "fp32 MFMA (v_mfma_f32_16x16x4_f32)"
     split = "fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulation (fp32 accuracy: tests/test_hip_ce.py)"
-    applies = mode == 2 or (getattr(a, "hidden", 0) == 64 and 81920 < getattr(a, "items", 0) <= 102400)
-    return split if applies else "fp32 MFMA (the split sweeps cover hidden 64 with 81,921..102,400 items)"
+    applies = mode == 2 or (getattr(a, "hidden", 0) == 64 and getattr(a, "items", 0) > 65536)
+    return split if applies else "fp32 MFMA (the split sweeps cover hidden 64 with more than 65,536 items)"
 
 
 def parse():

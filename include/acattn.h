@@ -229,8 +229,9 @@ int acattn_full_sort_ce_bwd(const acattn_ce_problem* p, const float* lse, const 
  * into three bf16 numbers and evaluates a product as the six bf16 MFMAs whose dropped remainder is below 2^-23 of
  * |a||b| -- one fp32 rounding; results are as close to fp64 as the exact-fp32 kernels' (tests/test_hip_ce.py).
  *   ACATTN_CE_PRODUCTS_FP32 (0)    exact fp32 MFMA everywhere (round 3's kernels; also ACATTN_CE_PRODUCTS=fp32)
- *   ACATTN_CE_PRODUCTS_DEFAULT (1) the split sweeps wherever six item tiles per wave cover the catalogue in one round
- *                                  (81,921 .. 102,400 items on 256 CUs), the fp32 kernels elsewhere
+ *   ACATTN_CE_PRODUCTS_DEFAULT (1) the split sweeps for catalogues of more than 65,536 items (waves of six item tiles: one
+ *                                  round of workgroups up to 98,304 items, one round + leftover tiles up to 102,400 --
+ *                                  the benchmark's 100,000 --, several rounds beyond), the fp32 kernels below
  *   ACATTN_CE_PRODUCTS_ALL (2)     the split sweeps for every catalogue size (tests)
  * Process-wide; returns the previous mode; any other value only queries.  Non-finite inputs: an infinite operand splits
  * into inf + nan, so an infinite logit becomes NaN instead of inf (the loss is non-finite either way). */

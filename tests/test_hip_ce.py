@@ -12,8 +12,9 @@ DEV = "cuda"
 
 # the split scheme [round 3] (six item tiles per wave on every CU + leftover tiles swept a quarter per wave, hidden 64,
 # 98,305 .. 102,400 items on 256 CUs): one leftover tile that is itself ragged, a ragged last one of many, all 256, one
-# past the scheme (falls back to seven tiles), and a batch that ends inside a row block
-SPLIT = [(40, 98305, 64), (33, 99990, 64), (48, 102400, 64), (16, 102401, 64), (70, 100000, 64),
+# past the scheme (round 3: seven fp32 tiles; [r4]: six-tile split-product waves in two rounds of workgroups), a batch that ends inside
+# a row block, [r4] fewer items than one round of six-tile waves and more than one round
+SPLIT = [(40, 98305, 64), (33, 99990, 64), (48, 102400, 64), (16, 102401, 64), (70, 100000, 64), (24, 70001, 64), (20, 131077, 64),
          (40, 100000, 128), (20, 49153, 128), (33, 57343, 128), (18, 110000, 128)]  # hidden 128: whole rounds of three tiles + leftovers
 
 
