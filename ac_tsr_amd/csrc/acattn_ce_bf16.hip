@@ -24,8 +24,12 @@
 //       (A[m = item c][k = row 8g + j]); B = rows by column (channel 16cb + c, rows 8g + j).  K = 32 rows: the sweep
 //       advances in SUPER-BLOCKS of 32 batch rows, P1 / soft-max / P2 per 16-row half.
 // The table operands (both orders, three planes each) stay in registers for the whole sweep: 288 of the 512 a wave has
-// at one wave per SIMD.  The batch rows are split once per launch by ce_split_rows_kernel into the exact operand
-// images (24 slots of 64 lanes x 16 bytes per super-block) and staged through LDS per super-block.
+// at one wave per SIMD, the second order pinned in accumulator registers (MFMAs read A / B from there directly; left to the
+// allocator the excess over 256 is spilled there and copied back in front of every use).  The batch rows are split once
+// per launch by ce_split_rows_kernel into the exact operand images (24 slots of 64 lanes x 16 bytes per super-block) and
+// reach LDS by LDS-DMA into a double buffer, one super-block ahead.  The target's one-hot is applied behind the sweep
+// (ce6_onehot_reduce_kernel); the catalogue's leftover tiles behind whole rounds of workgroups run on the same code with
+// one tile.  What was measured on the way: DESIGN.md 4.5, profiles/r04_ce6_stamps.txt.
 #include <stdlib.h>
 
 #include "acattn_common.h"

@@ -204,7 +204,7 @@ def _ce_errors(B, N, scale, mode, table_grad):
         lib.acattn_full_sort_ce_products(old)
 
 
-@pytest.mark.parametrize("B,N", [(512, 100000), (70, 99990), (37, 1000), (33, 385), (64, 5000), (45, 90000)])
+@pytest.mark.parametrize("B,N", [(512, 100000), (70, 99990), (37, 1000), (33, 385), (64, 5000), (45, 90000), (1030, 3000), (1, 64)])
 @pytest.mark.parametrize("scale", [0.02, 1.0])
 @pytest.mark.parametrize("table_grad", [True, False])
 def test_split_products_are_as_accurate_as_fp32_products(B, N, scale, table_grad):
