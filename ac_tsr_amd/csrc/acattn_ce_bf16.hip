@@ -139,6 +139,14 @@ __device__ unsigned long long g_ce6_stamps[4096 * 8];
 #else
 #define CE6_STAMP(k)
 #endif
+// -DCE6_STAMP_LEFT (with ACATTN_CE_STAMPS): slots 0..5 are re-used for the phases of the leftover units instead
+#if defined(ACATTN_CE_STAMPS) && defined(CE6_STAMP_LEFT)
+#define CE6_LSTAMP(k) CE6_STAMP(k)
+#define CE6_LRESET() do { for (int z_ = 0; z_ < 6; ++z_) cyc_[z_] = 0; } while (0)
+#else
+#define CE6_LSTAMP(k)
+#define CE6_LRESET()
+#endif
 
 template <int TILES>
 struct Ce6 {
@@ -467,17 +475,27 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
     __syncthreads();  // the parked tiles are free
     CE6_STAMP(5);
   }
-  auto store_dE = [&]() {  // the wave's d_table rows
+  // The wave's d_table rows.  A lane holds, per tile, 16 single floats of four different rows (item 4g + r, channel
+  // 16cb + c): stored as they stand that is 96 dword stores of four 64-byte pieces each -- 12,500 cycles per wave,
+  // 6 us of the launch (tools/gpu_ce6_stamps.sh, CE6_STAMP_LEFT=1).  Through the wave's parked-tile area instead: a tile
+  // as [16 items][64 channels], read back as whole rows, four 16-byte stores per lane and tile (256 contiguous bytes
+  // per 16 lanes).
+  auto store_dE = [&]() {
 #pragma unroll
-    for (int t = 0; t < TILES; ++t)
+    for (int t = 0; t < TILES; ++t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int item = item0 + 16 * t + 4 * g + r;
-        if (item < N) {
+      for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb) d_table[(size_t)item * CH + 16 * cb + c] = dE[t][cb][r];
-        }
+        for (int r = 0; r < 4; ++r) Pw[(4 * g + r) * ES + 16 * cb + c] = dE[t][cb][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the area is the wave's own)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = g + 4 * k, item = item0 + 16 * t + row;
+        const f4 v = *(const f4*)(Pw + row * ES + 4 * c);
+        if (item < N) *(f4*)(d_table + (size_t)item * CH + 4 * c) = v;
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next tile overwrites the area
+    }
   };
   if (WITH_TABLE_GRAD && n_left <= 0) store_dE();
   if (n_left > 0) {
@@ -542,10 +560,14 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
           for (int j = 0; j < 4; ++j) ec_n[cb][j] = P.table[(size_t)min(itx + 4 * g + j, N - 1) * CH + 16 * cb + c];
       }
     };
+    CE6_LRESET();
+    CE6_LSTAMP(-1);
     if (n_my > 0) request(first, true);
     if (WITH_TABLE_GRAD) store_dE();
+    CE6_LSTAMP(0);
     int cur_tile = -1;
     for (int k = 0; k < n_my; ++k) {
+      CE6_LSTAMP(-1);
       const int u = first + k * stride, tile = u / nsb, sb = u - tile * nsb;
       const int itx = gridDim.x * NW * C::ITEMS + 16 * tile;  // first item of the leftover tile
       const size_t vslab = (size_t)(gridDim.x + tile) * B;    // row offset of this tile's slab / partials
@@ -572,6 +594,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
           split8(x, Ec1[cb][0], Ec1[cb][1], Ec1[cb][2]);
         }
       }
+      CE6_LSTAMP(1);
       b8 Hq[HSLOTS];
 #pragma unroll
       for (int i = 0; i < HSLOTS; ++i) Hq[i] = Hn[i];
@@ -585,6 +608,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         const int un = first + (k + 1) * stride;
         request(un, un / nsb != tile);
       }
+      CE6_LSTAMP(2);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = 32 * sb + 16 * h + c;
@@ -622,6 +646,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         }
         b8 dlB1[3];
         split8(x8, dlB1[0], dlB1[1], dlB1[2]);
+        CE6_LSTAMP(3);
         if (WITH_TABLE_GRAD) {
 #pragma unroll
           for (int p = 0; p < 3; ++p)
@@ -639,6 +664,7 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
           for (int cb = 0; cb < 4; ++cb) *(f4*)(d_out_slab + (vslab + row) * CH + 16 * cb + 4 * g) = dh[cb];
           if (DIR && g == 0) part[vslab + row] = float2{m_w, s_w};
         }
+        CE6_LSTAMP(4);
       }
       if (WITH_TABLE_GRAD) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -655,7 +681,9 @@ __global__ void __launch_bounds__(64 * NW) ce6_bwd_kernel(const acattn_ce_proble
         CE6_TERMS(CE6_L3)
 #undef CE6_L3
       }
+      CE6_LSTAMP(5);
     }
+    CE6_LSTAMP(-1);
     if (WITH_TABLE_GRAD && tile_mine < n_left) {  // the four waves' shares of the tile's d_table rows meet in the parked-tile areas
       const int itx = gridDim.x * NW * C::ITEMS + 16 * tile_mine;
 #pragma unroll

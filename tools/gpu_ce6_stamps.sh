@@ -8,7 +8,7 @@ if [ "${1:-}" = "build" ]; then
   cd $R/ac_tsr_amd/csrc
   make -j8 > /dev/null
   mkdir -p $R/tools/tmp_libs
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -DACATTN_CE_STAMPS -DCE6_PIPE=${CE6_PIPE:-0} -c acattn_ce_bf16.hip -o /tmp/ce6_stamps.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$R/include -DACATTN_CE_STAMPS ${CE6_STAMP_LEFT:+-DCE6_STAMP_LEFT} -DCE6_PIPE=${CE6_PIPE:-0} -c acattn_ce_bf16.hip -o /tmp/ce6_stamps.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(ls *.o | grep -v '^acattn_ce_bf16.o$') /tmp/ce6_stamps.o -o $R/tools/tmp_libs/libacattn_ce6stamps.so
   echo built $R/tools/tmp_libs/libacattn_ce6stamps.so
   exit 0
