@@ -207,3 +207,41 @@ def test_spilling_streaming_forward_instantiations_are_the_ones_the_gpu_suite_co
                 spilling.add("<" + names[k["name"]].split("<", 1)[1].split(">")[0] + ">")
     assert n >= 48
     assert spilling <= covered, f"streaming-forward instantiations that spill without a >= 2 waves/SIMD oracle test: {spilling - covered}"
+
+
+def test_deferred_reductions_are_only_armed_inside_a_pass_that_will_flush_them():
+    """StepState.deferring() (state.py): on only when the trainer enabled it AND the running pass was opened with the leaves
+    of its walk (that pass flushes at its end); never on the frozen default, in the one-walk mode, or in a pass without
+    leaves -- otherwise a caller could be left holding unwritten gradient tensors.  Host logic only."""
+    import torch
+    from ac_tsr_amd.state import DEFAULT, StepState
+    st = StepState()
+    leaves = [torch.nn.Parameter(torch.zeros(3))]
+    assert not st.deferring()
+    with st.calibrated_pass(leaves):
+        assert not st.deferring()  # the trainer has not enabled it
+    st.defer_reductions = True
+    assert not st.deferring()  # no pass
+    with st.calibrated_pass():
+        assert not st.deferring()  # nobody would flush
+    with st.attack_pass(leaves):
+        assert st.deferring()
+        st.combined = object()
+        assert not st.deferring()  # the one-walk mode deposits gradients by hand
+        st.combined = None
+        with st.calibrated_pass():  # a nested pass without leaves does not inherit the outer one's
+            assert not st.deferring()
+        assert st.deferring()
+    assert not st.deferring() and st._deferred == [] and st._flush_leaves is None
+    # an exception inside the pass drops the queue instead of flushing it
+    try:
+        with st.calibrated_pass(leaves):
+            st._deferred.append({"dw": 1, "db": None})
+            raise KeyError("boom")
+    except KeyError:
+        pass
+    assert st._deferred == [] and st.pass_mode is None
+    # watch() ignores tensors that are not the last deferred sum's output
+    with st.calibrated_pass(leaves):
+        st.watch(torch.zeros(2), torch.zeros(1))
+    assert not DEFAULT.deferring()

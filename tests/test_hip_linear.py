@@ -72,3 +72,48 @@ def test_grouped_wgrad_equals_individual_calls():
         # (the number of partials per block follows the largest item of a group: same sums, different association)
         assert (dw - rw).abs().max() <= 2e-5 * rw.abs().max()
         assert (db is None) == (not wb) and (db is None or (db - rb).abs().max() <= 2e-5 * rb.abs().max())
+
+
+def test_deferred_stage_two_equals_the_one_call_form_bit_for_bit():
+    """[r4] acattn_linear_wgrad_grouped_partial + ONE acattn_linear_wgrad_reduce_many for items of several groups (different
+    M, sizes, with / without bias) and two plain row sums in the same launch, against acattn_linear_wgrad_grouped /
+    acattn_sum_rows: the same kernels' sums in the same order, so every element is identical."""
+    from types import SimpleNamespace
+    from ac_tsr_amd.state import StepState
+    g = torch.Generator().manual_seed(11)
+    groups = [[(25600, 64, 64, True), (25600, 64, 256, True), (25600, 256, 64, False)], [(512, 64, 64, True)], [(4099, 50, 200, True)]]
+    tensors = [[(torch.randn(M, K, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV), wb) for M, K, N, wb in grp] for grp in groups]
+    sums_in = [torch.randn(1600, 256, generator=g).to(DEV), torch.randn(1024, 2, 66, generator=g).to(DEV)]
+    ref = [ops.linear_wgrad_grouped(grp) for grp in tensors]
+    ref_sums = [ops.sum_rows(t, 0) for t in sums_in]
+    st = StepState()
+    st.defer_reductions = True
+    outs, leaves = [], []
+    with st.attack_pass([]):  # (opened with leaves = deferral armed; the flush at its end is replaced below)
+        assert st.deferring()
+        for grp in tensors:
+            outs.append(ops.linear_wgrad_grouped(grp, st))
+        sums = [ops.sum_rows0(t, st) for t in sums_in]
+        jobs = list(st._deferred)
+        assert len(jobs) == 5 + 2
+        # stand in for autograd: the returned tensors ARE the leaves' gradients
+        for grp in outs:
+            for gw, gb in grp:
+                for t in (gw, gb):
+                    if t is not None:
+                        leaves.append(SimpleNamespace(grad=t))
+        for s in sums:
+            st._deferred[[j.get("sum_out") for j in st._deferred].index(s.data_ptr())]["watch"].append(s.data_ptr())
+            leaves.append(SimpleNamespace(grad=s))
+        st._flush_leaves = leaves
+    torch.cuda.synchronize()
+    for grp_ref, grp_out in zip(ref, outs):
+        for (rw, rb), (gw, gb) in zip(grp_ref, grp_out):
+            assert torch.equal(rw, gw)
+            assert (rb is None and gb is None) or torch.equal(rb, gb)
+    for r, s in zip(ref_sums, sums):
+        assert torch.equal(r, s)
+    # a destination nobody adopted is an error, not silent garbage
+    with pytest.raises(RuntimeError, match="not adopted"):
+        with st.attack_pass([]):
+            ops.linear_wgrad_grouped(tensors[1], st)
