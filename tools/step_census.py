@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """step_census.py <kernel_trace.csv> [--sequence]: per-step kernel census from a rocprofv3 --kernel-trace of bench.py
 (--sequence: the launches of one timed step in order, with their durations).
-A step is delimited by ce_fwd_kernel (one launch per step).  bench.py runs the timed (full-schedule, graph) steps and then
+A step is delimited by adam_step_kernel (one launch per step).  bench.py runs the timed (full-schedule, graph) steps and then
 the plain trainer's; the census averages the steps that have the most common kernel count, i.e. the timed ones."""
 import collections
 import csv
@@ -11,9 +11,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 want_sequence = "--sequence" in sys.argv[2:]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 import re
-marks = [i for i, r in enumerate(rows) if re.search(r"(^|[ :])ce_fwd_kernel<", r["Kernel_Name"])]
-if len(marks) < 3:  # (AcBERT4Rec at hidden 256: materialised logits, no fused cross-entropy launch) one Adam launch per step
-    marks = [i for i, r in enumerate(rows) if "adam_step_kernel" in r["Kernel_Name"]]
+# one Adam launch per step ([r4]: the cross-entropy forward is no step marker any more -- bench.py's roofline_ce launches it
+# 40 times in a row)
+marks = [i for i, r in enumerate(rows) if "adam_step_kernel" in r["Kernel_Name"]]
+if len(marks) < 3:
+    marks = [i for i, r in enumerate(rows) if re.search(r"(^|[ :])ce_fwd_kernel<", r["Kernel_Name"])]
 spans = list(zip(marks, marks[1:]))
 mode = collections.Counter(b - a for a, b in spans).most_common(1)[0][0]
 spans = [(a, b) for a, b in spans if b - a == mode]
