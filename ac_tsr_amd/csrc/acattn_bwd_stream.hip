@@ -1215,13 +1215,24 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
       so += __shfl_xor(so, off);
       sd += __shfl_xor(sd, off);
     }
-    // every row of dq / dqa but the read one is zero
-    for (int row = part; row < L; row += PARTS) {
-      const size_t o = (rowbase + row) * H + hoff + d;
-      IO.dq[o] = row == i ? sq + da_o * vec[6][d] + da_d * vec[7][d] : 0.f;
-      if (!ACC) IO.dqa[o] = row == i ? sqa : 0.f;
+    // every row of dq / dqa but the read one is zero: 16-byte stores, 64 / (DH / 4) rows per instruction ([r4]: one dword per
+    // lane and row was 2 L / PARTS store instructions of 256 bytes -- 200 of them at L = 200)
+    if (ch == 0) {
+      constexpr int LPR = DH / 4, RPI = 64 / LPR;  // lanes per row slice, rows per instruction
+      const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+      for (int row = lane / LPR; row < L; row += RPI) {
+        if (row == i) continue;
+        const size_t o = (rowbase + row) * H + hoff + 4 * (lane % LPR);
+        *(f4*)(IO.dq + o) = z4;
+        if (!ACC) *(f4*)(IO.dqa + o) = z4;
+      }
     }
-    if (ACC && part == 0) IO.dqa[(rowbase + i) * H + hoff + d] += sqa;
+    if (part == 0) {
+      const size_t o = (rowbase + i) * H + hoff + d;
+      IO.dq[o] = sq + da_o * vec[6][d] + da_d * vec[7][d];
+      if (ACC) IO.dqa[o] += sqa;
+      else IO.dqa[o] = sqa;
+    }
     if (part != 0) continue;
     IO.dw_order_part[bh * stride_w + d] = da_o * vec[0][d];
     IO.dw_dist_part[bh * stride_w + d] = da_d * vec[0][d];
