@@ -950,8 +950,27 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ACC: dqa (all rows) and dka already hold the contribution of the mask cotangent (the mask-only path of the
 // row-resident kernel, which is linear in d M and independent of the context cotangents): the read row's chain is
 // added to them instead of overwriting.
+#ifdef ACATTN_ONEROW_STAMPS
+__device__ unsigned long long g_onerow_stamps[2048 * 8];
+#define OR_STAMP(k)                                                                \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    unsigned long long now_;                                                       \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    if ((k) >= 0) cyc_[(k) >= 0 ? (k) : 0] += now_ - last_;                        \
+    last_ = now_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#else
+#define OR_STAMP(k)
+#endif
+
 template <int DH, bool ACC, bool SLICED>
 __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_problem P, const acattn_bwd_io IO) {
+#ifdef ACATTN_ONEROW_STAMPS
+  unsigned long long cyc_[8] = {}, last_ = 0;
+#endif
+  OR_STAMP(-1);
   constexpr int D4 = DH / 4;
   __shared__ __attribute__((aligned(16))) float vec[8][DH];  // q, qa, d_ctx_att, d_ctx_cal, wko, wkd, w_order_q, w_dist_q
   __shared__ __attribute__((aligned(16))) float col[4][256];  // dS, dSa, d_o, d_d of every key
@@ -982,6 +1001,7 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
     vec[7][d] = P.w_dist[d];
   }
   __syncthreads();
+  OR_STAMP(0);
   RowScalars R;
   {
     float ao = 0.f, adv = 0.f;
@@ -1081,6 +1101,7 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
       cd4[r] = quad_sum(cd4[r]);
     }
   }
+  OR_STAMP(1);
   const f4 gl = load_seg(P.gate_logits + (rowbase + i) * L, j0, L, true);
   uint32_t eb4, ab4;
   tile_bits(F, t, g, i, L, causal, true, dead, eb4, ab4);
@@ -1113,6 +1134,7 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
     *(f4*)(&col[3][j0]) = d_d;
   }
 
+  OR_STAMP(2);
   // ---- key side: dk, dka, dv of the lane's 4 keys (rank one in the row's vectors) ------------------------------------------
   if constexpr (SLICED) {
 #pragma unroll
@@ -1157,6 +1179,7 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  OR_STAMP(3);
   // ---- gate-logit gradient: the read row carries dgl, every other row is zero --------------------------------------------------
   if (IO.dgate_logits && IO.dgate_summed) {
     // [r4] head-summed form ([B,L,L], zeroed by the launcher): this head's read row is ADDED, nothing else is touched
@@ -1175,6 +1198,7 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
     if (slice == 0) store_seg(gbase + (size_t)i * L, j0, L, true, dgl);
   }
   __syncthreads();  // col[] complete
+  OR_STAMP(4);
 
   // ---- query side and key halves of the parameter gradients: lane d sums over the keys --------------------------------------
   const int stride_w = IO.part_stride ? IO.part_stride : 2 * DH, stride_s = IO.part_stride ? IO.part_stride : 4;
@@ -1246,7 +1270,18 @@ __global__ void __launch_bounds__(64) acattn_bwd_onerow_kernel(const acattn_prob
     sm[2] = dsc_sum;
     sm[3] = 0.f;
   }
+  OR_STAMP(5);
+#ifdef ACATTN_ONEROW_STAMPS
+  if (lane == 0 && blockIdx.x < 2048)
+    for (int k = 0; k < 8; ++k) g_onerow_stamps[blockIdx.x * 8 + k] = cyc_[k];
+#endif
 }
+
+#ifdef ACATTN_ONEROW_STAMPS
+extern "C" int acattn_debug_onerow_stamps(unsigned long long* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_onerow_stamps), (size_t)n_words * 8);
+}
+#endif
 
 // Returns -100 when the one-row form does not apply.
 template <int DH>
